@@ -1,0 +1,109 @@
+"""Parity-test cases shared by the oracle cross-check (CPU) and the HIP parity tests (GPU)."""
+import numpy as np
+
+import readgen
+
+DEL_SCHEME = "[8]AGCTACGAATCG{8}TGGA{8}TGGA{8}ACTAGAT"
+DEL_RANDOM_SCHEME = DEL_SCHEME + "(12)TAGA"
+EXAMPLE_SCHEME = "[10]\nAGCTACGAATCG\n{6}\nTGGA\n{6}\nTGGA\n{6}\nACTAGAT\n(8)\nTAGA\n"
+CRISPR_SCHEME = "TTGTGGAAAGGACGAAACACCG{20}GTTTTAGAGCTAGAAATAGCAAGTT"
+FMTN_SCHEME = "[6]ACGTNNACGT{7}TTGNCA{5}GGATCC"
+NOSAMPLE_SCHEME = "GATTACA{9}CCTAGG{4}TTAACCGG"
+
+
+def build_case(name, seed=0, n=600):
+    """-> dict(scheme, samples {seq:id} | None, counted [list of seqs] | None, kwargs, reads)"""
+    rng = np.random.default_rng(seed + 1000 * (abs(hash(name)) % 1000 if False else sum(map(ord, name))))
+    c = dict(name=name, kwargs={})
+    if name == "del_exact":
+        c["scheme"] = DEL_SCHEME
+        s = readgen.make_set(rng, 4, 8, 3)
+        c["samples"] = {x: "S%d" % i for i, x in enumerate(s)}
+        c["counted"] = [readgen.make_set(rng, 50, 8, 2) for _ in range(3)]
+        c["kwargs"] = dict(max_sample=0, max_barcode=0, max_constant=0)
+        c["reads"] = readgen.gen_reads(rng, DEL_SCHEME, n, 100, s, c["counted"], p_sub=0.004, p_n=0.001)
+    elif name == "del_mismatch_quality":
+        c["scheme"] = DEL_SCHEME
+        s = readgen.make_set(rng, 4, 8, 3)
+        c["samples"] = {x: "S%d" % i for i, x in enumerate(s)}
+        c["counted"] = [readgen.make_set(rng, 60, 8, 2) for _ in range(3)]
+        c["kwargs"] = dict(min_quality=20.0)
+        c["reads"] = readgen.gen_reads(rng, DEL_SCHEME, n, 100, s, c["counted"], p_sub=0.02, p_n=0.004)
+    elif name == "del_dense_ties":
+        # many close references: ties and ambiguous corrections are common
+        c["scheme"] = DEL_SCHEME
+        s = readgen.make_set(rng, 6, 8, 1)
+        c["samples"] = {x: "S%d" % i for i, x in enumerate(s)}
+        c["counted"] = [readgen.make_set(rng, 300, 8, 1) for _ in range(3)]
+        c["kwargs"] = dict(max_barcode=2, max_sample=2, max_constant=7, min_quality=25.5)
+        c["reads"] = readgen.gen_reads(rng, DEL_SCHEME, n, 100, s, c["counted"], p_sub=0.05, p_n=0.01)
+    elif name == "del_random":
+        c["scheme"] = DEL_RANDOM_SCHEME
+        s = readgen.make_set(rng, 3, 8, 3)
+        c["samples"] = {x: "S%d" % i for i, x in enumerate(s)}
+        c["counted"] = [readgen.make_set(rng, 5, 8, 3) for _ in range(3)]
+        c["reads"] = readgen.gen_reads(rng, DEL_RANDOM_SCHEME, n, 110, s, c["counted"], p_sub=0.01, p_n=0.002,
+                                       dup_frac=0.4)
+    elif name == "example_files":
+        c["scheme"] = EXAMPLE_SCHEME
+        c["samples"] = None
+        c["counted"] = [["CAGAGAC", "TGATTGC"], ["ATGAAAT", "GCGCCAT"], ["GATAGCT", "TTAGCTA"]]
+        c["reads"] = readgen.gen_reads(rng, EXAMPLE_SCHEME, n, 80, ["AAAAAAAAAA", "CCCCCCCCCC"], c["counted"],
+                                       p_sub=0.02, p_n=0.003, dup_frac=0.1, var_len=True)
+    elif name == "example_files_samples":
+        c["scheme"] = EXAMPLE_SCHEME
+        c["samples"] = {"AGCATAC": "Sample_name_1", "AACTTAC": "Sample_name_2"}
+        c["counted"] = [["CAGAGAC", "TGATTGC"], ["ATGAAAT", "GCGCCAT"], ["GATAGCT", "TTAGCTA"]]
+        c["kwargs"] = dict(min_quality=18.0)
+        c["reads"] = readgen.gen_reads(rng, EXAMPLE_SCHEME, n, 78, ["AGCATACGGG", "AACTTACTTT"], c["counted"],
+                                       p_sub=0.02, p_n=0.003)
+    elif name == "crispr":
+        c["scheme"] = CRISPR_SCHEME
+        c["samples"] = None
+        c["counted"] = [readgen.make_set(rng, 400, 20, 3)]
+        c["reads"] = readgen.gen_reads(rng, CRISPR_SCHEME, n, 100, None, c["counted"], p_sub=0.03, p_n=0.003)
+    elif name == "fmtn":
+        # scheme with N positions: [AGCT] in the regex, wildcard in repair, regions_string shift (Q9)
+        c["scheme"] = FMTN_SCHEME
+        s = readgen.make_set(rng, 3, 6, 2)
+        c["samples"] = {x: "S%d" % i for i, x in enumerate(s)}
+        c["counted"] = [readgen.make_set(rng, 20, 7, 2), readgen.make_set(rng, 10, 5, 2)]
+        c["kwargs"] = dict(min_quality=22.0)
+        c["reads"] = readgen.gen_reads(rng, FMTN_SCHEME, n, 64, s, c["counted"], p_sub=0.03, p_n=0.02, var_len=True)
+    elif name == "nosample_with_sample_file":
+        # sample file given but no [n] in the scheme: counts are discarded yet matched (Q11)
+        c["scheme"] = NOSAMPLE_SCHEME
+        c["samples"] = {"ACGTACGT": "X"}
+        c["counted"] = [readgen.make_set(rng, 30, 9, 2), readgen.make_set(rng, 8, 4, 2)]
+        c["reads"] = readgen.gen_reads(rng, NOSAMPLE_SCHEME, n, 50, None, c["counted"], p_sub=0.02, p_n=0.003)
+    elif name == "nosample":
+        c["scheme"] = NOSAMPLE_SCHEME
+        c["samples"] = None
+        c["counted"] = [readgen.make_set(rng, 30, 9, 2), readgen.make_set(rng, 8, 4, 2)]
+        c["kwargs"] = dict(min_quality=30.5)
+        c["reads"] = readgen.gen_reads(rng, NOSAMPLE_SCHEME, n, 50, None, c["counted"], p_sub=0.02, p_n=0.003)
+    elif name == "refs_with_n_and_ragged":
+        # references containing N and of mixed lengths (Q6, Q7)
+        c["scheme"] = DEL_SCHEME
+        c["samples"] = {"ACGTACGT": "a", "ACGTACGN": "b", "TTTT": "c", "GGGGGGGGGG": "d"}
+        c["counted"] = [["ACGTACGT", "ACGTACGA", "ACNTACGT", "CCCCCC", "GGGGGGGGGGG"],
+                        readgen.make_set(rng, 20, 8, 2) + ["NNNNNNNN"][:0],
+                        readgen.make_set(rng, 20, 8, 2) + ["ACGTNNNN"]]
+        c["reads"] = readgen.gen_reads(rng, DEL_SCHEME, n, 90, list(c["samples"]), c["counted"], p_sub=0.03,
+                                       p_n=0.02)
+    elif name == "other_chars":
+        # bytes outside ACGTN in reads: mismatch everywhere, never wildcard
+        c["scheme"] = DEL_SCHEME
+        s = readgen.make_set(rng, 4, 8, 3)
+        c["samples"] = {x: "S%d" % i for i, x in enumerate(s)}
+        c["counted"] = [readgen.make_set(rng, 40, 8, 2) for _ in range(3)]
+        c["reads"] = readgen.gen_reads(rng, DEL_SCHEME, n, 100, s, c["counted"], p_sub=0.01, p_n=0.002,
+                                       p_other=0.01)
+    else:
+        raise KeyError(name)
+    return c
+
+
+ALL_CASES = ["del_exact", "del_mismatch_quality", "del_dense_ties", "del_random", "example_files",
+             "example_files_samples", "crispr", "fmtn", "nosample_with_sample_file", "nosample",
+             "refs_with_n_and_ragged", "other_chars"]
