@@ -1,0 +1,181 @@
+/*
+ * barcode_count_hip.h -- C ABI of the MI355X (gfx950) barcode match/count engine.
+ *
+ * Drop-in boundary for ONE path of Roco-scientist/NGS-Barcode-Count (crate
+ * barcode-count v0.11.1): the per-read match/count loop of src/parse.rs
+ * (SequenceParser::parse, parse.rs:53-76, and everything it calls) together
+ * with Results::add_count (info.rs:735-808) and the six SequenceErrors
+ * counters (info.rs:16-139).  The reference exposes no FFI of its own; these
+ * entry points are what a Rust `extern "C"` block in the reference's
+ * src/main.rs would bind in place of the rayon worker fan-out
+ * (main.rs:93-120) -- see INTEGRATION.md for that binding.
+ *
+ * Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ * All functions return BC_OK (0) or a negative status; bc_last_error() gives
+ * the message of the calling thread's last failure.  Nothing here falls back
+ * to a CPU implementation: an engine cannot be created without a HIP device.
+ */
+#ifndef BARCODE_COUNT_HIP_H
+#define BARCODE_COUNT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BC_OK 0
+#define BC_ERR_INVALID (-1)     /* the reference would return Err / panic on this input */
+#define BC_ERR_UNSUPPORTED (-2) /* valid for the reference, not handled by this engine (message says what) */
+#define BC_ERR_HIP (-3)         /* HIP runtime failure */
+#define BC_ERR_NOMEM (-4)
+#define BC_ERR_STATE (-5)       /* call order violated */
+
+/* outcome counters: SequenceErrors (info.rs:16-23) in Display order (info.rs:141-172),
+ * then two engine-side extras */
+enum {
+  BC_MATCHED = 0,
+  BC_CONSTANT_REGION = 1,
+  BC_SAMPLE_BARCODE = 2,
+  BC_BARCODE = 3,
+  BC_DUPLICATES = 4,
+  BC_LOW_QUALITY = 5,
+  BC_TOTAL_READS = 6, /* reads submitted (input.rs:128-130 total_reads, minus the gz off-by-one) */
+  BC_UNSUPPORTED_READS = 7, /* reads the engine cannot score exactly (non-ASCII bytes); always 0 for FASTQ */
+  BC_NCOUNTERS = 8
+};
+
+typedef struct bc_plan bc_plan;     /* compiled scheme + known barcode sets + error budgets (host) */
+typedef struct bc_engine bc_engine; /* one run on one GPU: device tables, stream, results */
+typedef struct bc_synth bc_synth;   /* counter-based synthetic read generator */
+
+const char *bc_version(void);
+const char *bc_last_error(void);
+
+/* ---- static run description ------------------------------------------------------------ */
+
+/* SequenceFormat::parse_format_file (info.rs:215-310); `text` = content of the scheme file. */
+bc_plan *bc_plan_create(const char *scheme_text, size_t len);
+void bc_plan_destroy(bc_plan *p);
+/* SequenceFormat fields (info.rs:176-187) */
+const char *bc_plan_format_string(const bc_plan *p);
+const char *bc_plan_regions_string(const bc_plan *p);
+const char *bc_plan_regex_string(const bc_plan *p);
+uint32_t bc_plan_length(const bc_plan *p);
+uint32_t bc_plan_constant_region_length(const bc_plan *p);
+uint32_t bc_plan_barcode_num(const bc_plan *p);
+uint32_t bc_plan_barcode_length(const bc_plan *p, uint32_t i);
+int32_t bc_plan_sample_length(const bc_plan *p); /* -1 = None */
+int bc_plan_has_random(const bc_plan *p);
+int bc_plan_has_sample(const bc_plan *p);
+
+/* BarcodeConversions::sample_barcode_file_conversion + get_sample_seqs (info.rs:364-381, 435-441) */
+int bc_plan_load_sample_csv(bc_plan *p, const char *csv_text, size_t len);
+/* BarcodeConversions::barcode_file_conversion + get_barcode_seqs (info.rs:390-433, 444-456) */
+int bc_plan_load_counted_csv(bc_plan *p, const char *csv_text, size_t len);
+/* what the loaders insert, one entry at a time (a later duplicate sequence replaces the ID) */
+int bc_plan_add_sample(bc_plan *p, const char *seq, const char *id);
+int bc_plan_add_counted(bc_plan *p, uint32_t barcode_index, const char *seq, const char *id);
+/* known sets in engine index order (index = position in first-insertion order) */
+uint32_t bc_plan_n_samples(const bc_plan *p);
+const char *bc_plan_sample_seq(const bc_plan *p, uint32_t i);
+const char *bc_plan_sample_id(const bc_plan *p, uint32_t i);
+uint32_t bc_plan_n_counted(const bc_plan *p, uint32_t barcode_index);
+const char *bc_plan_counted_seq(const bc_plan *p, uint32_t barcode_index, uint32_t i);
+const char *bc_plan_counted_id(const bc_plan *p, uint32_t barcode_index, uint32_t i);
+
+/* MaxSeqErrors::new (info.rs:490-543); -1 = None (use 20 % of the length) */
+int bc_plan_set_max_errors(bc_plan *p, int sample_errors, int barcode_errors, int constant_errors);
+uint32_t bc_plan_max_constant_errors(const bc_plan *p);          /* info.rs:565 */
+uint32_t bc_plan_max_sample_errors(const bc_plan *p);            /* info.rs:589 */
+uint32_t bc_plan_max_barcode_errors(const bc_plan *p, uint32_t i); /* info.rs:613 */
+/* free-standing form for the reference's doctest values: out[0]=constant, out[1]=sample, out[2..]=barcodes */
+void bc_max_seq_errors(int sample_errors, int sample_size, int barcode_errors, const uint16_t *barcode_sizes,
+                       uint32_t n_barcodes, int constant_errors, uint16_t constant_region_size, uint16_t *out);
+/* --min-quality (arguments.rs:111-118); 0 = filter off (parse.rs:98) */
+int bc_plan_set_min_quality(bc_plan *p, float min_quality);
+/* integer score-sum threshold equivalent to the f32 mean test of parse.rs:352-355 for a run of n
+ * bases: low quality <=> sum(scores) < T_n */
+uint32_t bc_plan_quality_threshold(const bc_plan *p, uint32_t run_len);
+
+/* ---- engine ---------------------------------------------------------------------------- */
+
+/* Number of u32 entries of the dense per-(sample, barcode tuple) counter table the plan needs
+ * (product of the set sizes); 0 when the plan cannot use a dense table. */
+uint64_t bc_plan_table_entries(const bc_plan *p);
+
+/* Replaces SequenceParser::new (parse.rs:28-52) for all workers of one device.  `hip_stream`
+ * (a hipStream_t) may be NULL: the engine then owns a stream.  `table_mem` may point to
+ * caller-owned device memory of bc_plan_table_entries()*4 bytes (zeroed by the caller), so the
+ * caller can reduce it across devices with RCCL; NULL lets the engine allocate it. */
+bc_engine *bc_engine_create(const bc_plan *p, int device_id, void *hip_stream, void *table_mem);
+void bc_engine_destroy(bc_engine *e);
+
+/* One batch of reads = the records the reference's workers pop from SharedMutData.seq
+ * (parse.rs:78-86), already split into the sequence line and the quality line.
+ * Layout: read i occupies bytes [i*stride, i*stride+len_i) of `seq` and of `qual`
+ * (ASCII, as in the FASTQ); len_i = lens[i] or read_len when lens is NULL.  qual may be NULL
+ * only when the quality filter is off.  Both buffers must be 16-byte aligned.
+ * _device: pointers are device memory; the call only enqueues work on the engine's stream.
+ * _host: pointers are host memory; the engine stages them through pinned buffers with
+ * hipMemcpyAsync on a side stream and returns when the host buffers may be reused. */
+int bc_engine_submit_device(bc_engine *e, const void *d_seq, const void *d_qual, const void *d_lens, uint32_t stride,
+                            uint32_t read_len, uint64_t n_reads);
+int bc_engine_submit_host(bc_engine *e, const void *seq, const void *qual, const uint16_t *lens, uint32_t stride,
+                          uint32_t read_len, uint64_t n_reads);
+int bc_engine_sync(bc_engine *e);
+/* zero the table and the counters (a fresh Results::new, info.rs:678) */
+int bc_engine_reset(bc_engine *e);
+
+/* SequenceErrors values (u64; the reference wraps at 2^32, info.rs:17-22) */
+int bc_engine_counters(bc_engine *e, uint64_t out[BC_NCOUNTERS]);
+/* device pointers, for cross-device reduction by the caller (RCCL sum over u32 / u64) */
+void *bc_engine_table_ptr(bc_engine *e);
+void *bc_engine_counters_ptr(bc_engine *e);
+uint64_t bc_engine_table_entries(const bc_engine *e);
+
+/* Compacts the non-zero table entries on the device; rows are then readable in any order.
+ * A row = (sample index, barcode index per counted barcode, count): the (sample, tuple, count)
+ * triples Results holds (info.rs:661-665), with indices into the plan's known sets. */
+int bc_engine_finish(bc_engine *e, uint64_t *n_rows);
+int bc_engine_rows(bc_engine *e, uint64_t first, uint64_t n, uint32_t *sample_idx, uint32_t *barcode_idx,
+                   uint64_t *count);
+
+/* HIP-event timing of the match/count kernel on the engine's stream (for the roofline) */
+int bc_engine_timing(bc_engine *e, int enable);
+int bc_engine_kernel_ms(bc_engine *e, double *total_ms, uint64_t *launches);
+
+/* fix_error (parse.rs:553-593) on the device: nearest unique candidate under Hamming distance
+ * with 'N' wildcards, common-prefix compare.  Returns the candidate index, -1 for None,
+ * or < -1 on error (BC_ERR_* - 1). */
+int64_t bc_fix_error(const char *mismatch_seq, const char *const *possible_seqs, uint64_t n, uint16_t mismatches,
+                     int device_id);
+
+/* ---- synthetic workloads (bench + full-size parity) -------------------------------------- */
+
+typedef struct bc_synth_params {
+  uint64_t seed;
+  uint32_t read_len;     /* R; construct start uniform in [0, R-L-1] */
+  uint32_t p_sub;        /* per-base substitution probability * 2^32 */
+  uint32_t p_n;          /* per-base 'N' probability * 2^32 */
+  uint32_t p_lowq;       /* probability * 2^32 that one barcode of a read gets low qualities */
+  uint8_t phred_lo, phred_hi;   /* default Phred range, inclusive */
+  uint8_t lowq_lo, lowq_hi;     /* low-quality Phred range, inclusive */
+  uint64_t n_molecules;  /* 0: every read is its own molecule; else reads are draws from this many
+                            molecules (PCR duplicates) */
+} bc_synth_params;
+
+bc_synth *bc_synth_create(const bc_plan *p, const bc_synth_params *params);
+void bc_synth_destroy(bc_synth *s);
+int bc_synth_generate_host(bc_synth *s, uint64_t first_read, uint64_t n_reads, void *seq, void *qual, uint32_t stride);
+int bc_synth_generate_device(bc_synth *s, int device_id, void *hip_stream, uint64_t first_read, uint64_t n_reads,
+                             void *d_seq, void *d_qual, uint32_t stride);
+/* deterministic reference set: n distinct k-mers, pairwise Hamming distance >= min_dist;
+ * out receives n*(k+1) bytes (NUL-terminated strings) */
+int bc_synth_make_set(uint64_t seed, uint32_t n, uint32_t k, uint32_t min_dist, char *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,387 @@
+"""ngs-barcode-count_amd -- MI355X (gfx950) engine for the per-read match/count path of
+Roco-scientist/NGS-Barcode-Count, behind the C ABI of include/barcode_count_hip.h.
+
+Import name: `ngs_barcode_count_amd` (the shim module at the repo root maps it onto this
+directory, whose name is not a Python identifier).
+
+Two layers:
+  * Plan / Engine / Synth -- thin ctypes wrappers of the C ABI;
+  * SequenceFormat, BarcodeConversions, MaxSeqErrors, SequenceErrors, Results, SequenceParser --
+    host-side mirror of the reference's own types for this path (src/info.rs, src/parse.rs), same
+    names and argument meaning, so callers and tests read like the reference.
+There is no CPU implementation in this package: without the HIP library everything raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import COUNTER_NAMES, SynthParams
+
+__all__ = ["Plan", "Engine", "Synth", "SequenceFormat", "BarcodeConversions", "MaxSeqErrors", "SequenceErrors",
+           "Results", "SequenceParser", "fix_error", "BarcodeCountError", "COUNTER_NAMES"]
+
+
+class BarcodeCountError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (status %d)" % (msg, code))
+        self.code = code
+
+
+def _check(lib, rc):
+    if rc != 0:
+        raise BarcodeCountError(rc, _lib.last_error(lib))
+
+
+def _opt(v):
+    return -1 if v is None else int(v)
+
+
+class Plan:
+    """Compiled scheme + known barcode sets + error budgets (bc_plan)."""
+
+    def __init__(self, scheme_text, lib=None):
+        self._lib = lib or _lib.load()
+        b = scheme_text.encode()
+        self._p = self._lib.bc_plan_create(b, len(b))
+        if not self._p:
+            raise BarcodeCountError(_lib.BC_ERR_INVALID, _lib.last_error(self._lib))
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            self._lib.bc_plan_destroy(self._p)
+            self._p = None
+
+    # SequenceFormat fields (info.rs:176-187)
+    format_string = property(lambda s: s._lib.bc_plan_format_string(s._p).decode())
+    regions_string = property(lambda s: s._lib.bc_plan_regions_string(s._p).decode())
+    regex_string = property(lambda s: s._lib.bc_plan_regex_string(s._p).decode())
+    length = property(lambda s: s._lib.bc_plan_length(s._p))
+    constant_region_length = property(lambda s: s._lib.bc_plan_constant_region_length(s._p))
+    barcode_num = property(lambda s: s._lib.bc_plan_barcode_num(s._p))
+    barcode_lengths = property(lambda s: [s._lib.bc_plan_barcode_length(s._p, i) for i in range(s.barcode_num)])
+    random_barcode = property(lambda s: bool(s._lib.bc_plan_has_random(s._p)))
+    sample_barcode = property(lambda s: bool(s._lib.bc_plan_has_sample(s._p)))
+
+    @property
+    def sample_length_option(self):
+        v = self._lib.bc_plan_sample_length(self._p)
+        return None if v < 0 else v
+
+    def load_sample_csv(self, text):
+        b = text.encode()
+        _check(self._lib, self._lib.bc_plan_load_sample_csv(self._p, b, len(b)))
+
+    def load_counted_csv(self, text):
+        b = text.encode()
+        _check(self._lib, self._lib.bc_plan_load_counted_csv(self._p, b, len(b)))
+
+    def add_sample(self, seq, sample_id):
+        _check(self._lib, self._lib.bc_plan_add_sample(self._p, seq.encode(), sample_id.encode()))
+
+    def add_counted(self, barcode_index, seq, barcode_id):
+        _check(self._lib, self._lib.bc_plan_add_counted(self._p, barcode_index, seq.encode(), barcode_id.encode()))
+
+    def samples(self):
+        """[(sequence, id)] in engine index order"""
+        L, p = self._lib, self._p
+        return [(L.bc_plan_sample_seq(p, i).decode(), L.bc_plan_sample_id(p, i).decode())
+                for i in range(L.bc_plan_n_samples(p))]
+
+    def counted(self, barcode_index):
+        L, p = self._lib, self._p
+        return [(L.bc_plan_counted_seq(p, barcode_index, i).decode(), L.bc_plan_counted_id(p, barcode_index, i).decode())
+                for i in range(L.bc_plan_n_counted(p, barcode_index))]
+
+    def set_max_errors(self, sample_errors=None, barcode_errors=None, constant_errors=None):
+        _check(self._lib, self._lib.bc_plan_set_max_errors(self._p, _opt(sample_errors), _opt(barcode_errors),
+                                                           _opt(constant_errors)))
+
+    def set_min_quality(self, q):
+        _check(self._lib, self._lib.bc_plan_set_min_quality(self._p, float(q)))
+
+    max_constant_errors = property(lambda s: s._lib.bc_plan_max_constant_errors(s._p))
+    max_sample_errors = property(lambda s: s._lib.bc_plan_max_sample_errors(s._p))
+    max_barcode_errors = property(lambda s: [s._lib.bc_plan_max_barcode_errors(s._p, i)
+                                             for i in range(s.barcode_num)])
+
+    def quality_threshold(self, run_len):
+        return self._lib.bc_plan_quality_threshold(self._p, run_len)
+
+    @property
+    def table_entries(self):
+        n = self._lib.bc_plan_table_entries(self._p)
+        if n == 0:
+            raise BarcodeCountError(_lib.BC_ERR_UNSUPPORTED, _lib.last_error(self._lib))
+        return n
+
+
+class Engine:
+    """One run on one GPU (bc_engine).  `table` may be a caller-owned zeroed device buffer of
+    plan.table_entries u32 (e.g. a torch tensor's data_ptr()) so it can be reduced with RCCL."""
+
+    def __init__(self, plan, device=0, stream=None, table_ptr=None):
+        self._lib = plan._lib
+        self.plan = plan
+        self._e = self._lib.bc_engine_create(plan._p, int(device), stream, table_ptr)
+        if not self._e:
+            raise BarcodeCountError(_lib.BC_ERR_HIP, _lib.last_error(self._lib))
+
+    def close(self):
+        if getattr(self, "_e", None):
+            self._lib.bc_engine_destroy(self._e)
+            self._e = None
+
+    __del__ = close
+
+    def submit_device(self, d_seq, d_qual, n_reads, stride, read_len, d_lens=None):
+        _check(self._lib, self._lib.bc_engine_submit_device(self._e, d_seq, d_qual, d_lens, stride, read_len, n_reads))
+
+    def submit_host(self, seq, qual, stride, read_len, lens=None):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        n = seq.size // stride
+        qp = None
+        if qual is not None:
+            qual = np.ascontiguousarray(qual, dtype=np.uint8)
+            qp = qual.ctypes.data
+        lp = None
+        if lens is not None:
+            lens = np.ascontiguousarray(lens, dtype=np.uint16)
+            lp = lens.ctypes.data
+        _check(self._lib, self._lib.bc_engine_submit_host(self._e, seq.ctypes.data, qp, lp, stride, read_len, n))
+
+    def sync(self):
+        _check(self._lib, self._lib.bc_engine_sync(self._e))
+
+    def reset(self):
+        _check(self._lib, self._lib.bc_engine_reset(self._e))
+
+    def counters(self):
+        out = (C.c_uint64 * 8)()
+        _check(self._lib, self._lib.bc_engine_counters(self._e, out))
+        return dict(zip(COUNTER_NAMES, [int(x) for x in out]))
+
+    table_ptr = property(lambda s: s._lib.bc_engine_table_ptr(s._e))
+    counters_ptr = property(lambda s: s._lib.bc_engine_counters_ptr(s._e))
+    table_entries = property(lambda s: s._lib.bc_engine_table_entries(s._e))
+
+    def trace(self, d_outcome_u8, d_index_u64):
+        """per-read outcome / dense index written by the next submits (tests); None disables"""
+        _check(self._lib, self._lib.bc_engine_trace(self._e, d_outcome_u8, d_index_u64))
+
+    def timing(self, enable=True):
+        _check(self._lib, self._lib.bc_engine_timing(self._e, 1 if enable else 0))
+
+    def kernel_ms(self):
+        ms, n = C.c_double(), C.c_uint64()
+        _check(self._lib, self._lib.bc_engine_kernel_ms(self._e, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def rows(self):
+        """-> (sample_idx[n], barcode_idx[n, barcode_num], count[n]) of the non-zero table entries"""
+        n = C.c_uint64()
+        _check(self._lib, self._lib.bc_engine_finish(self._e, C.byref(n)))
+        n = n.value
+        nb = max(self.plan.barcode_num, 1)
+        s = np.zeros(n, dtype=np.uint32)
+        b = np.zeros((n, nb), dtype=np.uint32)
+        c = np.zeros(n, dtype=np.uint64)
+        if n:
+            _check(self._lib, self._lib.bc_engine_rows(self._e, 0, n, s.ctypes.data, b.ctypes.data, c.ctypes.data))
+        return s, b[:, :self.plan.barcode_num], c
+
+    def result_rows(self):
+        """sorted [(sample key, "b1,b2,..", count)] with sequences as keys, like Results (info.rs:661-665)"""
+        s, b, c = self.rows()
+        samples = [x for x, _ in self.plan.samples()] if self.plan.sample_barcode else ["barcode"]
+        sets = [[x for x, _ in self.plan.counted(i)] for i in range(self.plan.barcode_num)]
+        out = []
+        for i in range(len(c)):
+            out.append((samples[s[i]], ",".join(sets[j][b[i, j]] for j in range(len(sets))), int(c[i])))
+        return sorted(out)
+
+
+class Synth:
+    """Counter-based synthetic read generator; identical on host and device."""
+
+    def __init__(self, plan, seed, read_len=100, p_sub=0.0, p_n=0.0, p_lowq=0.0, phred=(30, 40), lowq=(2, 15),
+                 n_molecules=0):
+        self._lib = plan._lib
+        self.plan = plan
+        f = lambda p: min(int(round(p * 4294967296.0)), 4294967295)
+        self.params = SynthParams(seed, read_len, f(p_sub), f(p_n), f(p_lowq), phred[0], phred[1], lowq[0], lowq[1],
+                                  n_molecules)
+        self._s = self._lib.bc_synth_create(plan._p, C.byref(self.params))
+        if not self._s:
+            raise BarcodeCountError(_lib.BC_ERR_INVALID, _lib.last_error(self._lib))
+
+    def __del__(self):
+        if getattr(self, "_s", None):
+            self._lib.bc_synth_destroy(self._s)
+            self._s = None
+
+    def generate_host(self, first, n, stride=None):
+        stride = stride or self.params.read_len
+        seq = np.empty(n * stride, dtype=np.uint8)
+        qual = np.empty(n * stride, dtype=np.uint8)
+        _check(self._lib, self._lib.bc_synth_generate_host(self._s, first, n, seq.ctypes.data, qual.ctypes.data, stride))
+        return seq, qual
+
+    def generate_device(self, device, stream, first, n, d_seq, d_qual, stride=None):
+        stride = stride or self.params.read_len
+        _check(self._lib, self._lib.bc_synth_generate_device(self._s, device, stream, first, n, d_seq, d_qual, stride))
+
+
+def make_set(seed, n, k, min_dist=1, lib=None):
+    lib = lib or _lib.load()
+    buf = C.create_string_buffer(n * (k + 1))
+    rc = lib.bc_synth_make_set(seed, n, k, min_dist, buf)
+    _check(lib, rc)
+    raw = buf.raw
+    return [raw[i * (k + 1):i * (k + 1) + k].decode() for i in range(n)]
+
+
+def fix_error(mismatch_seq, possible_seqs, mismatches, device=0, lib=None):
+    """fix_error (parse.rs:553-593) on the GPU: the unique nearest candidate or None."""
+    lib = lib or _lib.load()
+    possible_seqs = list(possible_seqs)
+    arr = (C.c_char_p * max(len(possible_seqs), 1))(*[s.encode() for s in possible_seqs])
+    r = lib.bc_fix_error(mismatch_seq.encode(), arr, len(possible_seqs), mismatches, device)
+    if r < -1:
+        raise BarcodeCountError(int(r) + 1, _lib.last_error(lib))
+    return None if r < 0 else possible_seqs[r]
+
+
+# ------------------------------------------------------------------------------------------------
+# host-side mirror of the reference's types for this path
+# ------------------------------------------------------------------------------------------------
+class SequenceFormat:
+    """info.rs:176-310"""
+
+    def __init__(self, plan):
+        self.plan = plan
+        for f in ("format_string", "regions_string", "length", "constant_region_length", "barcode_num",
+                  "barcode_lengths", "sample_length_option", "random_barcode", "sample_barcode"):
+            setattr(self, f, getattr(plan, f))
+
+    @classmethod
+    def parse_format_file(cls, format_path):
+        with open(format_path) as fh:
+            return cls(Plan(fh.read()))
+
+    @classmethod
+    def from_text(cls, text):
+        return cls(Plan(text))
+
+    def __str__(self):  # Display, info.rs:313-335
+        key, seen = "", set()
+        names = {"S": "\nS: Sample barcode", "B": "\nB: Counted barcode", "C": "\nC: Constant region",
+                 "R": "\nR: Random barcode"}
+        for ch in self.regions_string:
+            if ch not in seen:
+                seen.add(ch)
+                key += names.get(ch, "")
+        return "-FORMAT-\n%s\n%s%s" % (self.format_string, self.regions_string, key)
+
+
+class BarcodeConversions:
+    """info.rs:338-457; the sets live in the plan of the SequenceFormat they belong to"""
+
+    def __init__(self, sequence_format):
+        self.plan = sequence_format.plan
+
+    def sample_barcode_file_conversion(self, barcode_path):
+        with open(barcode_path) as fh:
+            self.plan.load_sample_csv(fh.read())
+
+    def barcode_file_conversion(self, barcode_path, barcode_num=None):
+        with open(barcode_path) as fh:
+            self.plan.load_counted_csv(fh.read())
+
+    samples_barcode_hash = property(lambda s: dict(s.plan.samples()))
+    sample_seqs = property(lambda s: {x for x, _ in s.plan.samples()})
+    counted_barcodes_hash = property(lambda s: [dict(s.plan.counted(i)) for i in range(s.plan.barcode_num)])
+    counted_barcode_seqs = property(lambda s: [{x for x, _ in s.plan.counted(i)} for i in range(s.plan.barcode_num)])
+
+
+class MaxSeqErrors:
+    """info.rs:461-616"""
+
+    def __init__(self, sample_errors_option, sample_barcode_size_option, barcode_errors_option, barcode_sizes,
+                 constant_errors_option, constant_region_size, min_quality, lib=None):
+        lib = lib or _lib.load()
+        n = len(barcode_sizes)
+        sizes = (C.c_uint16 * max(n, 1))(*barcode_sizes)
+        out = (C.c_uint16 * (2 + max(n, 1)))()
+        lib.bc_max_seq_errors(_opt(sample_errors_option), _opt(sample_barcode_size_option), _opt(barcode_errors_option),
+                              sizes, n, _opt(constant_errors_option), constant_region_size, out)
+        self._c, self._s, self._b = out[0], out[1], [out[2 + i] for i in range(n)]
+        self.options = (sample_errors_option, barcode_errors_option, constant_errors_option)
+        self.min_quality = min_quality
+
+    def max_constant_errors(self):
+        return self._c
+
+    def max_sample_errors(self):
+        return self._s
+
+    def max_barcode_errors(self):
+        return list(self._b)
+
+
+class SequenceErrors:
+    """info.rs:16-172; filled from the engine's device counters"""
+    FIELDS = ["matched", "constant_region", "sample_barcode", "barcode", "duplicates", "low_quality"]
+
+    def __init__(self):
+        for f in self.FIELDS:
+            setattr(self, f, 0)
+
+    def update(self, counters):
+        for f in self.FIELDS:
+            setattr(self, f, counters[f] & 0xFFFFFFFF)  # AtomicU32 (info.rs:17-22)
+
+    def __str__(self):  # Display, info.rs:141-172
+        g = lambda v: "{:,}".format(v)
+        return ("Correctly matched sequences: %s\nConstant region mismatches:  %s\nSample barcode mismatches:   %s\n"
+                "Counted barcode mismatches:  %s\nDuplicates:                  %s\nLow quality barcodes:        %s" %
+                (g(self.matched), g(self.constant_region), g(self.sample_barcode), g(self.barcode), g(self.duplicates),
+                 g(self.low_quality)))
+
+
+class Results:
+    """info.rs:669-808: results_hashmap[sample][\"b1,b2,..\"] = count"""
+
+    def __init__(self, samples_barcode_hash, random_barcode, sample_barcode):
+        self.results_hashmap = {}
+        if samples_barcode_hash:
+            for s in samples_barcode_hash:
+                self.results_hashmap[s] = {}
+        elif not sample_barcode:
+            self.results_hashmap["barcode"] = {}
+
+    def fill(self, rows):
+        for sample, tup, count in rows:
+            self.results_hashmap.setdefault(sample, {})[tup] = count
+
+
+class SequenceParser:
+    """parse.rs:15-163.  The worker pool of main.rs:93-120 becomes one engine per GPU; the queue of
+    packed records (SharedMutData.seq) becomes batches of sequence / quality lines."""
+
+    def __init__(self, results, sequence_errors, sequence_format, max_errors, min_quality_score, device=0):
+        self.results = results
+        self.sequence_errors = sequence_errors
+        self.plan = sequence_format.plan
+        so, bo, co = max_errors.options
+        self.plan.set_max_errors(so, bo, co)
+        self.plan.set_min_quality(min_quality_score)
+        self.engine = Engine(self.plan, device)
+
+    def parse(self, seq, qual, stride, read_len, lens=None):
+        """one batch of reads from host arrays; call finish() after the last batch"""
+        self.engine.submit_host(seq, qual, stride, read_len, lens)
+
+    def finish(self):
+        self.sequence_errors.update(self.engine.counters())
+        self.results.fill(self.engine.result_rows())

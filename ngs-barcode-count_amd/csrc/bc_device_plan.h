@@ -1,0 +1,74 @@
+// bc_device_plan.h -- the compiled scheme as the GPU sees it (plain data, uploaded once per engine).
+//
+// Device-side form of what every reference worker clones from main.rs:95-102:
+// SequenceFormat (info.rs:176-187), MaxSeqErrors (info.rs:461-472) and the known-barcode
+// sets of BarcodeConversions (info.rs:338-343).
+#pragma once
+#include <stdint.h>
+
+namespace bc {
+
+constexpr int kMaxGroups = 18;    // sample + 16 counted barcodes + random
+constexpr int kMaxSteps = 384;    // shift/apply steps per position class
+constexpr int kMaxRuns = 40;      // quality runs of regions_string
+constexpr int kClasses = 5;       // A, C, T, G constants + scheme-N ([AGCT]) positions
+constexpr int kMaxNW = 10;        // 32-base words per read: reads up to 320 bases
+constexpr uint32_t kFail = 0xFFFFFFFFu;
+constexpr uint16_t kFail16 = 0xFFFFu;
+
+// letter code of an ASCII base: (c >> 1) & 3  ->  A=0 C=1 T=2 G=3
+enum { kCodeA = 0, kCodeC = 1, kCodeT = 2, kCodeG = 3, kClassFmtN = 4 };
+
+enum GroupType : uint32_t { kGroupSample = 0, kGroupBarcode = 1, kGroupRandom = 2 };
+enum SetMode : uint32_t {
+  kSetNone = 0,    // no known set: the capture itself is the key (raw-key mode)
+  kSetDirect = 1,  // 4^len-entry correction table (len <= 10): one gather per barcode
+  kSetHash = 2,    // exact hash lookup, then wave-cooperative Hamming search
+  kSetScan = 3     // wave-cooperative Hamming search only
+};
+
+struct DevGroup {
+  uint32_t type;       // GroupType
+  uint32_t off;        // offset of the capture inside a match
+  uint32_t len;        // capture length (<= 32)
+  uint32_t mode;       // SetMode
+  uint32_t n_refs;
+  uint32_t max_err;    // MaxSeqErrors budget of this group
+  uint32_t hmask;      // hash slots - 1
+  uint32_t has_odd;    // set holds refs with 'N' or of a different length (no single-N shortcut)
+  uint64_t table_stride;  // multiplier of this group's index in the dense counter index
+  const uint16_t* dtable; // kSetDirect: fix_error result for every N-free capture, kFail16 = None
+  const uint32_t* r1;     // reference bit planes (bit i = base i): ASCII bit 1
+  const uint32_t* r2;     //                                          ASCII bit 2
+  const uint32_t* rn;     // 'N' positions of the reference
+  const uint8_t* rlen;    // reference length
+  const uint64_t* hkeys;  // kSetHash: q1 | q2 << 32 of references usable for exact lookup
+  const uint32_t* hvals;  // index or kFail for an empty slot
+};
+
+struct DevPlan {
+  uint32_t L;           // format length = bytes one match spans
+  uint32_t RL;          // strlen(regions_string) (= L minus scheme-N positions, Appendix A Q9)
+  uint32_t n_groups;
+  uint32_t max_const;   // MaxSeqErrors::max_constant_errors
+  uint32_t nb;          // bits of the bit-sliced mismatch counters: values 0..2^nb-1, then overflow
+  uint32_t quality_on;  // min_quality > 0 (parse.rs:98)
+  uint32_t n_runs;
+  uint32_t discard_counts;  // sample file given but no sample group: add_count hits a temporary (info.rs:762-766)
+  uint32_t has_fmtn;
+  uint32_t n_steps[kClasses];
+  // step = shift right by (s & 31); if (s & 0x80) combine the shifted vector into the accumulator
+  uint32_t steps[kClasses][kMaxSteps];
+  uint32_t run_off[kMaxRuns];   // quality runs in regions_string coordinates
+  uint32_t run_len[kMaxRuns];
+  uint32_t run_thr[kMaxRuns];   // low <=> sum(scores) < thr   (f32-exact, Appendix A Q10)
+  DevGroup groups[kMaxGroups];  // sample group first (if any), then counted barcodes in order, then random
+};
+
+// outcome of one read, in counter order (barcode_count_hip.h BC_*)
+enum Outcome : uint32_t {
+  kMatched = 0, kConstantRegion = 1, kSampleBarcode = 2, kBarcode = 3, kDuplicate = 4, kLowQuality = 5,
+  kUnsupported = 7
+};
+
+}  // namespace bc

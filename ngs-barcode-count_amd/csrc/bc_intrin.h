@@ -1,0 +1,66 @@
+// bc_intrin.h -- the handful of gfx950 VALU instructions the lane code leans on.
+// Under hipcc these are the hardware instructions; the plain-C++ forms exist only so that
+// tests/emu can run the SAME lane logic on the host against the oracle (never a product path).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define BC_HD __host__ __device__ __forceinline__
+#else
+#define BC_HD inline
+#endif
+
+namespace bc {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// v_alignbit_b32: ({hi,lo} >> (s & 31)) low 32 bits
+BC_HD uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t s) { return __builtin_amdgcn_alignbit(hi, lo, s); }
+// v_alignbyte_b32: ({hi,lo} >> 8*(s & 3)) low 32 bits
+BC_HD uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t s) { return __builtin_amdgcn_alignbyte(hi, lo, s); }
+// v_dot4_u32_u8: sum of the four byte products + c
+BC_HD uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_udot4(a, b, c, false); }
+// v_perm_b32: selector bytes 0-3 pick bytes of lo, 4-7 bytes of hi
+BC_HD uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+// v_sad_u8: sum of absolute byte differences + c
+BC_HD uint32_t sad_u8(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_sad_u8(a, b, c); }
+BC_HD uint32_t popc(uint32_t x) { return __builtin_popcount(x); }
+BC_HD uint32_t ctz(uint32_t x) { return __builtin_ctz(x); }
+#else
+BC_HD uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t s) {
+  return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (s & 31));
+}
+BC_HD uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t s) {
+  return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * (s & 3)));
+}
+BC_HD uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) {
+  for (int i = 0; i < 4; ++i) c += ((a >> (8 * i)) & 0xFF) * ((b >> (8 * i)) & 0xFF);
+  return c;
+}
+BC_HD uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) {
+  uint64_t src = (((uint64_t)hi) << 32) | lo;
+  uint32_t r = 0;
+  for (int i = 0; i < 4; ++i) {
+    uint32_t s = (sel >> (8 * i)) & 0xFF;
+    uint32_t b = s < 8 ? (uint32_t)((src >> (8 * s)) & 0xFF) : (s >= 0x0D ? 0xFFu : 0u);
+    r |= b << (8 * i);
+  }
+  return r;
+}
+BC_HD uint32_t sad_u8(uint32_t a, uint32_t b, uint32_t c) {
+  for (int i = 0; i < 4; ++i) {
+    int x = (a >> (8 * i)) & 0xFF, y = (b >> (8 * i)) & 0xFF;
+    c += (uint32_t)(x > y ? x - y : y - x);
+  }
+  return c;
+}
+BC_HD uint32_t popc(uint32_t x) { return (uint32_t)__builtin_popcount(x); }
+BC_HD uint32_t ctz(uint32_t x) { return (uint32_t)__builtin_ctz(x); }
+#endif
+
+// bytes that are zero -> 0x80 in that byte
+BC_HD uint32_t zero_bytes(uint32_t v) { return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; }
+// low `n` bits set, n in [0, 32]
+BC_HD uint32_t lowmask(uint32_t n) { return n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u); }
+
+}  // namespace bc

@@ -1,0 +1,548 @@
+// bc_plan.cpp -- scheme compiler, known-barcode loaders and error budgets (host side of the
+// C ABI).  Mirrors, for the hot path's static inputs, the reference's
+//   SequenceFormat::parse_format_file   info.rs:215-310
+//   BarcodeConversions::*               info.rs:364-456
+//   MaxSeqErrors::new                   info.rs:490-543
+// and lowers them to the bit-plane programs the gfx950 kernels run (bc_device_plan.h).
+#include "bc_plan.hpp"
+
+#include <string.h>
+
+#include <algorithm>
+
+#include "../../include/barcode_count_hip.h"
+
+namespace bc {
+
+static thread_local std::string g_error;
+void set_error(const std::string& msg) { g_error = msg; }
+const char* get_error() { return g_error.c_str(); }
+
+namespace {
+
+// str::lines(): split on '\n', a trailing "\r" of each line is dropped, no empty last line
+std::vector<std::string> rust_lines(const char* text, size_t len) {
+  std::vector<std::string> out;
+  size_t i = 0;
+  while (i < len) {
+    size_t j = i;
+    while (j < len && text[j] != '\n') ++j;
+    size_t e = j;
+    if (e > i && text[e - 1] == '\r') --e;
+    out.emplace_back(text + i, e - i);
+    i = j + 1;
+  }
+  return out;
+}
+
+inline bool is_base_ci(char c) {
+  switch (c) {
+    case 'A': case 'T': case 'G': case 'C': case 'a': case 't': case 'g': case 'c': return true;
+    default: return false;
+  }
+}
+
+enum TokKind { kTokNone, kTokSample, kTokBarcode, kTokRandom, kTokNs, kTokBases };
+
+// one token of (?i)(\{\d+\})|(\[\d+\])|(\(\d+\))|N+|[ATGC]+  (info.rs:232); anything else is skipped
+TokKind lex(const std::string& s, size_t i, size_t& tok_len) {
+  const char c = s[i];
+  const char* open = "{[(";
+  const char* close = "}])";
+  for (int k = 0; k < 3; ++k) {
+    if (c == open[k]) {
+      size_t j = i + 1;
+      while (j < s.size() && s[j] >= '0' && s[j] <= '9') ++j;
+      if (j == i + 1 || j >= s.size() || s[j] != close[k]) return kTokNone;
+      tok_len = j + 1 - i;
+      return k == 0 ? kTokBarcode : (k == 1 ? kTokSample : kTokRandom);
+    }
+  }
+  if (c == 'N' || c == 'n') {
+    size_t j = i;
+    while (j < s.size() && (s[j] == 'N' || s[j] == 'n')) ++j;
+    tok_len = j - i;
+    return kTokNs;
+  }
+  if (is_base_ci(c)) {
+    size_t j = i;
+    while (j < s.size() && is_base_ci(s[j])) ++j;
+    tok_len = j - i;
+    return kTokBases;
+  }
+  return kTokNone;
+}
+
+std::vector<std::string> split_take(const std::string& line, size_t want) {
+  std::vector<std::string> f;
+  size_t s = 0;
+  for (size_t i = 0; i <= line.size() && f.size() < want; ++i) {
+    if (i == line.size() || line[i] == ',') {
+      f.emplace_back(line, s, i - s);
+      s = i + 1;
+    }
+  }
+  return f;
+}
+
+}  // namespace
+}  // namespace bc
+
+using namespace bc;
+
+void bc_plan::recompute_budgets() {
+  // main.rs:55-63 feeds SequenceFormat's fields to MaxSeqErrors::new
+  std::vector<uint16_t> sizes(barcode_lengths.begin(), barcode_lengths.end());
+  std::vector<uint16_t> out(2 + sizes.size() + 1);
+  bc_max_seq_errors(opt_sample, sample_length, opt_barcode, sizes.data(), (uint32_t)sizes.size(), opt_constant,
+                    (uint16_t)constant_region_length, out.data());
+  max_constant = out[0];
+  max_sample = out[1];
+  max_barcode.assign(out.begin() + 2, out.begin() + 2 + sizes.size());
+}
+
+uint32_t bc_plan::quality_threshold(uint32_t n) const {
+  // smallest integer score sum s with !(fl32(s / n) < min_quality): the f32 mean test of
+  // parse.rs:352-355 is then exactly "sum < T_n" (sums of u8 scores are exact in f32)
+  if (n == 0) return 0;
+  uint32_t lo = 0, hi = 255u * n + 1u;  // hi: the test can never pass -> everything below is low
+  const float fn = (float)n;
+  auto low = [&](uint32_t s) { return ((float)s / fn) < min_quality; };
+  if (!low(0)) return 0;
+  if (low(255u * n)) return hi;
+  lo = 0;
+  hi = 255u * n;  // low(lo) true, low(hi) false
+  while (hi - lo > 1) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (low(mid))
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return hi;
+}
+
+static bool pack_ref(const std::string& s, uint32_t& r1, uint32_t& r2, uint32_t& rn) {
+  r1 = r2 = rn = 0;
+  for (size_t i = 0; i < s.size(); ++i) {
+    const char c = s[i];
+    if (c == 'N') {
+      rn |= 1u << i;
+    } else if (c == 'A' || c == 'C' || c == 'G' || c == 'T') {
+      r1 |= (uint32_t)((c >> 1) & 1) << i;
+      r2 |= (uint32_t)((c >> 2) & 1) << i;
+    } else {
+      return false;
+    }
+  }
+  return true;
+}
+
+bool bc_plan::lower(HostDevPlan& out) const {
+  if (!unsupported.empty()) {
+    set_error("unsupported scheme: " + unsupported);
+    return false;
+  }
+  if (length == 0 || length > (uint32_t)kMaxNW * 32u) {
+    set_error("unsupported scheme: format length must be 1.." + std::to_string(kMaxNW * 32));
+    return false;
+  }
+  if (random_barcode) {
+    set_error("unsupported scheme: random barcode (PCR-duplicate collapse) needs the sparse key path, not built yet");
+    return false;
+  }
+  if (sample_barcode && samples.size() == 0) {
+    set_error("unsupported plan: sample barcode in the scheme without a sample barcode file (raw-key mode)");
+    return false;
+  }
+  if (barcode_num > 0 && !counted_loaded) {
+    set_error("unsupported plan: counted barcodes without a counted barcode file (raw-key mode)");
+    return false;
+  }
+  if (max_constant > 31) {
+    set_error("unsupported plan: --max-errors-constant above 31");
+    return false;
+  }
+  DevPlan& P = out.plan;
+  memset(&P, 0, sizeof(P));
+  P.L = length;
+  P.RL = (uint32_t)regions_string.size();
+  P.max_const = max_constant;
+  uint32_t nb = 0;
+  while ((1u << nb) <= (uint32_t)max_constant) ++nb;  // counters hold 0 .. 2^nb-1 >= max_constant
+  P.nb = nb;
+  P.quality_on = min_quality > 0.0f ? 1u : 0u;  // parse.rs:98
+
+  // shift/apply programs, one per position class
+  std::vector<uint32_t> where[kClasses];
+  for (uint32_t p = 0; p < pos.size(); ++p) {
+    if (pos[p].kind == kPosConst)
+      where[(pos[p].letter >> 1) & 3].push_back(p);
+    else if (pos[p].kind == kPosFmtN)
+      where[kClassFmtN].push_back(p);
+  }
+  for (int c = 0; c < kClasses; ++c) {
+    uint32_t cur = 0, n = 0;
+    for (uint32_t p : where[c]) {
+      uint32_t delta = p - cur;
+      while (delta > 31) {
+        if (n >= (uint32_t)kMaxSteps) break;
+        P.steps[c][n++] = 31;
+        delta -= 31;
+      }
+      if (n >= (uint32_t)kMaxSteps) {
+        set_error("unsupported scheme: too many constant positions");
+        return false;
+      }
+      P.steps[c][n++] = delta | 0x80u;
+      cur = p;
+    }
+    P.n_steps[c] = n;
+  }
+  P.has_fmtn = where[kClassFmtN].empty() ? 0u : 1u;
+
+  // quality runs: maximal stretches of one non-'C' letter of regions_string (parse.rs:340-372)
+  {
+    uint32_t n = 0;
+    size_t i = 0;
+    const std::string& r = regions_string;
+    while (i < r.size()) {
+      size_t j = i;
+      while (j < r.size() && r[j] == r[i]) ++j;
+      if (r[i] != 'C' && j < r.size()) {  // a run ending the string is never evaluated (Appendix A Q9)
+        if (n >= (uint32_t)kMaxRuns) {
+          set_error("unsupported scheme: more than " + std::to_string(kMaxRuns) + " barcode runs");
+          return false;
+        }
+        P.run_off[n] = (uint32_t)i;
+        P.run_len[n] = (uint32_t)(j - i);
+        P.run_thr[n] = quality_threshold((uint32_t)(j - i));
+        ++n;
+      }
+      i = j;
+    }
+    P.n_runs = n;
+  }
+
+  // groups: sample first, then counted barcodes in order (the dense index is row-major in that order)
+  struct Pending {
+    const FormatGroup* g;
+    const KnownSet* set;
+    uint32_t max_err;
+  };
+  std::vector<Pending> order;
+  for (const auto& g : groups)
+    if (g.type == kGroupSample) order.push_back({&g, &samples, max_sample});
+  for (uint32_t b = 1; b <= barcode_num; ++b)
+    for (const auto& g : groups)
+      if (g.type == kGroupBarcode && g.number == b) order.push_back({&g, &counted[b - 1], max_barcode[b - 1]});
+  if (order.size() > (size_t)kMaxGroups) {
+    set_error("unsupported scheme: too many barcode groups");
+    return false;
+  }
+  P.n_groups = (uint32_t)order.size();
+  out.sets.assign(order.size(), HostSet());
+  out.n_samples = sample_barcode ? (uint32_t)samples.size() : 1u;
+  // Results::add_count with a sample file but no sample group: the key "barcode" is absent, the
+  // increment lands in a temporary, yet the read counts as matched (info.rs:762-766)
+  P.discard_counts = (!sample_barcode && samples.size() > 0) ? 1u : 0u;
+  unsigned __int128 entries = 1;
+  for (int i = (int)order.size() - 1; i >= 0; --i) {
+    const Pending& pd = order[i];
+    DevGroup& G = P.groups[i];
+    G.type = pd.g->type;
+    G.off = pd.g->off;
+    G.len = pd.g->len;
+    if (G.len == 0 || G.len > 32) {
+      set_error("unsupported scheme: barcode groups must be 1..32 bases");
+      return false;
+    }
+    G.n_refs = (uint32_t)pd.set->size();
+    G.max_err = pd.max_err;
+    G.table_stride = (uint64_t)entries;
+    entries *= G.n_refs;
+    if (entries > ((unsigned __int128)1 << 40)) {
+      set_error("unsupported plan: dense counter table above 2^40 entries");
+      return false;
+    }
+    HostSet& H = out.sets[i];
+    H.r1.resize(G.n_refs);
+    H.r2.resize(G.n_refs);
+    H.rn.resize(G.n_refs);
+    H.rlen.resize(G.n_refs);
+    G.has_odd = 0;
+    for (uint32_t j = 0; j < G.n_refs; ++j) {
+      const std::string& s = pd.set->seqs[j];
+      if (s.size() > 32 || !pack_ref(s, H.r1[j], H.r2[j], H.rn[j])) {
+        set_error("unsupported plan: known barcode '" + s + "' (only A,C,G,T,N and at most 32 bases)");
+        return false;
+      }
+      H.rlen[j] = (uint8_t)s.size();
+      if (H.rn[j] || s.size() != G.len) G.has_odd = 1;
+    }
+    if (G.len <= 10 && G.n_refs < 65535u) {
+      G.mode = kSetDirect;
+    } else {
+      G.mode = kSetHash;
+      uint32_t slots = 16;
+      while (slots < 2 * G.n_refs) slots <<= 1;
+      G.hmask = slots - 1;
+      H.hkeys.assign(slots, 0);
+      H.hvals.assign(slots, kFail);
+      for (uint32_t j = 0; j < G.n_refs; ++j) {
+        if (H.rn[j] || H.rlen[j] != G.len) continue;  // only an identical string is an exact member
+        const uint64_t key = (uint64_t)H.r1[j] | ((uint64_t)H.r2[j] << 32);
+        // same mixer as bc::hash64 in bc_lane.h
+        uint64_t x = key;
+        x ^= x >> 30;
+        x *= 0xBF58476D1CE4E5B9ull;
+        x ^= x >> 27;
+        x *= 0x94D049BB133111EBull;
+        x ^= x >> 31;
+        uint32_t h = (uint32_t)x & G.hmask;
+        while (H.hvals[h] != kFail) h = (h + 1) & G.hmask;
+        H.hkeys[h] = key;
+        H.hvals[h] = j;
+      }
+    }
+  }
+  out.table_entries = (uint64_t)entries;
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI: plan
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* bc_version(void) { return "barcode-count-hip 0.1.0 (gfx950)"; }
+const char* bc_last_error(void) { return bc::get_error(); }
+
+bc_plan* bc_plan_create(const char* text, size_t len) {
+  if (!text) {
+    set_error("bc_plan_create: null scheme text");
+    return nullptr;
+  }
+  // info.rs:218-222: drop lines starting with '#', concatenate the rest
+  std::string data;
+  for (const auto& l : rust_lines(text, len))
+    if (l.empty() || l[0] != '#') data += l;
+
+  bc_plan* p = new bc_plan();
+  uint32_t off = 0;
+  for (size_t i = 0; i < data.size();) {
+    size_t tl = 0;
+    const TokKind k = lex(data, i, tl);
+    if (k == kTokNone) {
+      ++i;
+      continue;
+    }
+    const std::string tok = data.substr(i, tl);
+    i += tl;
+    if (k == kTokSample || k == kTokBarcode || k == kTokRandom) {
+      const uint32_t digits = (uint32_t)strtoul(tok.c_str() + 1, nullptr, 10);  // info.rs:252-259
+      std::string name;
+      char region;
+      uint32_t type;
+      if (k == kTokSample) {
+        if (p->sample_barcode) {  // second (?P<sample>..): Regex::new fails (info.rs:308)
+          set_error("sequence format: duplicate capture group name 'sample'");
+          delete p;
+          return nullptr;
+        }
+        p->sample_barcode = true;
+        p->sample_length = (int32_t)digits;
+        name = "sample";
+        region = 'S';
+        type = kGroupSample;
+      } else if (k == kTokBarcode) {
+        p->barcode_num++;
+        p->barcode_lengths.push_back(digits);
+        name = "barcode" + std::to_string(p->barcode_num);
+        region = 'B';
+        type = kGroupBarcode;
+      } else {
+        if (p->random_barcode) {
+          set_error("sequence format: duplicate capture group name 'random'");
+          delete p;
+          return nullptr;
+        }
+        p->random_barcode = true;
+        name = "random";
+        region = 'R';
+        type = kGroupRandom;
+      }
+      p->regex_string += "(?P<" + name + ">.{" + std::to_string(digits) + "})";  // info.rs:263-267
+      p->groups.push_back({type, k == kTokBarcode ? p->barcode_num : 0u, off, digits});
+      for (uint32_t d = 0; d < digits; ++d) {  // info.rs:283-286
+        p->regions_string.push_back(region);
+        p->format_string.push_back('N');
+        p->pos.push_back({kPosGroup, 0, (int)p->groups.size() - 1});
+      }
+      off += digits;
+    } else if (tok.find('N') != std::string::npos) {
+      // info.rs:287-295: only the upper-case N's are counted, nothing goes to regions_string
+      const uint32_t n = (uint32_t)std::count(tok.begin(), tok.end(), 'N');
+      p->regex_string += "[AGCT]{" + std::to_string(n) + "}";
+      p->format_string += tok;
+      if (n != tok.size()) p->unsupported = "lower-case 'n' in the sequence format";
+      for (uint32_t d = 0; d < n; ++d) p->pos.push_back({kPosFmtN, 0, -1});
+      off += n;
+    } else {
+      // info.rs:296-305: constant region; the regex gets the upper-cased letters
+      for (char c : tok) {
+        const char u = (char)(c & ~0x20);
+        p->regex_string.push_back(u);
+        p->regions_string.push_back('C');
+        p->pos.push_back({kPosConst, u, -1});
+        if (c != u) p->unsupported = "lower-case letters in the sequence format";
+      }
+      p->format_string += tok;
+      p->constant_region_length += (uint32_t)tok.size();
+      off += (uint32_t)tok.size();
+    }
+  }
+  p->length = (uint32_t)p->format_string.size();  // info.rs:307
+  p->counted.resize(p->barcode_num);
+  p->recompute_budgets();
+  return p;
+}
+
+void bc_plan_destroy(bc_plan* p) { delete p; }
+const char* bc_plan_format_string(const bc_plan* p) { return p->format_string.c_str(); }
+const char* bc_plan_regions_string(const bc_plan* p) { return p->regions_string.c_str(); }
+const char* bc_plan_regex_string(const bc_plan* p) { return p->regex_string.c_str(); }
+uint32_t bc_plan_length(const bc_plan* p) { return p->length; }
+uint32_t bc_plan_constant_region_length(const bc_plan* p) { return p->constant_region_length; }
+uint32_t bc_plan_barcode_num(const bc_plan* p) { return p->barcode_num; }
+uint32_t bc_plan_barcode_length(const bc_plan* p, uint32_t i) {
+  return i < p->barcode_lengths.size() ? p->barcode_lengths[i] : 0;
+}
+int32_t bc_plan_sample_length(const bc_plan* p) { return p->sample_length; }
+int bc_plan_has_random(const bc_plan* p) { return p->random_barcode; }
+int bc_plan_has_sample(const bc_plan* p) { return p->sample_barcode; }
+
+int bc_plan_load_sample_csv(bc_plan* p, const char* text, size_t len) {
+  // info.rs:364-381: skip the header, first two comma-separated fields, no trimming
+  bool first = true;
+  for (const auto& l : rust_lines(text, len)) {
+    if (first) {
+      first = false;
+      continue;
+    }
+    auto f = split_take(l, 2);
+    if (f.size() == 2)
+      p->samples.insert(f[0], f[1]);
+    else
+      p->samples.insert("", "");  // collect_tuple() == None (info.rs:374-375)
+  }
+  return BC_OK;
+}
+
+int bc_plan_load_counted_csv(bc_plan* p, const char* text, size_t len) {
+  // info.rs:390-433
+  std::vector<bool> seen(p->barcode_num, false);
+  std::vector<bc::KnownSet> sets(p->barcode_num);
+  bool first = true;
+  for (const auto& l : rust_lines(text, len)) {
+    if (first) {
+      first = false;
+      continue;
+    }
+    auto f = split_take(l, 3);
+    if (f.size() != 3) f.assign(3, std::string());
+    // usize::from_str: optional '+', then digits
+    const std::string& t = f[2];
+    size_t d0 = (!t.empty() && t[0] == '+') ? 1 : 0;
+    bool ok = t.size() > d0;
+    for (size_t i = d0; i < t.size(); ++i) ok = ok && t[i] >= '0' && t[i] <= '9';
+    if (!ok) {
+      set_error("Third column of barcode file contains something other than an integer: " + t);
+      return BC_ERR_INVALID;
+    }
+    const unsigned long v = strtoul(t.c_str() + d0, nullptr, 10);
+    if (v == 0 || v > p->barcode_num) {  // `0 - 1` / out-of-bounds index: the reference panics
+      set_error("barcode number " + t + " outside 1..=" + std::to_string(p->barcode_num));
+      return BC_ERR_INVALID;
+    }
+    seen[v - 1] = true;
+    sets[v - 1].insert(f[0], f[1]);
+  }
+  for (uint32_t x = 0; x < p->barcode_num; ++x) {
+    if (!seen[x]) {  // info.rs:420-431
+      set_error("Barcode conversion file missing barcode numers [" + std::to_string(x) + "] in the third column");
+      return BC_ERR_INVALID;
+    }
+  }
+  for (uint32_t x = 0; x < p->barcode_num; ++x)
+    for (size_t j = 0; j < sets[x].size(); ++j) p->counted[x].insert(sets[x].seqs[j], sets[x].ids[j]);
+  p->counted_loaded = true;
+  return BC_OK;
+}
+
+int bc_plan_add_sample(bc_plan* p, const char* seq, const char* id) {
+  p->samples.insert(seq, id);
+  return BC_OK;
+}
+
+int bc_plan_add_counted(bc_plan* p, uint32_t bi, const char* seq, const char* id) {
+  if (bi >= p->barcode_num) {
+    set_error("bc_plan_add_counted: barcode index out of range");
+    return BC_ERR_INVALID;
+  }
+  p->counted[bi].insert(seq, id);
+  p->counted_loaded = true;
+  return BC_OK;
+}
+
+uint32_t bc_plan_n_samples(const bc_plan* p) { return (uint32_t)p->samples.size(); }
+const char* bc_plan_sample_seq(const bc_plan* p, uint32_t i) {
+  return i < p->samples.size() ? p->samples.seqs[i].c_str() : nullptr;
+}
+const char* bc_plan_sample_id(const bc_plan* p, uint32_t i) {
+  return i < p->samples.size() ? p->samples.ids[i].c_str() : nullptr;
+}
+uint32_t bc_plan_n_counted(const bc_plan* p, uint32_t bi) {
+  return bi < p->counted.size() ? (uint32_t)p->counted[bi].size() : 0;
+}
+const char* bc_plan_counted_seq(const bc_plan* p, uint32_t bi, uint32_t i) {
+  return (bi < p->counted.size() && i < p->counted[bi].size()) ? p->counted[bi].seqs[i].c_str() : nullptr;
+}
+const char* bc_plan_counted_id(const bc_plan* p, uint32_t bi, uint32_t i) {
+  return (bi < p->counted.size() && i < p->counted[bi].size()) ? p->counted[bi].ids[i].c_str() : nullptr;
+}
+
+void bc_max_seq_errors(int sample_errors, int sample_size, int barcode_errors, const uint16_t* barcode_sizes,
+                       uint32_t n_barcodes, int constant_errors, uint16_t constant_region_size, uint16_t* out) {
+  // info.rs:499-532: an explicit value wins, otherwise 20 % of the size (integer division)
+  out[1] = sample_size >= 0 ? (uint16_t)(sample_errors >= 0 ? sample_errors : sample_size / 5) : (uint16_t)0;
+  for (uint32_t i = 0; i < n_barcodes; ++i)
+    out[2 + i] = (uint16_t)(barcode_errors >= 0 ? barcode_errors : barcode_sizes[i] / 5);
+  out[0] = (uint16_t)(constant_errors >= 0 ? constant_errors : constant_region_size / 5);
+}
+
+int bc_plan_set_max_errors(bc_plan* p, int sample_errors, int barcode_errors, int constant_errors) {
+  p->opt_sample = sample_errors;
+  p->opt_barcode = barcode_errors;
+  p->opt_constant = constant_errors;
+  p->recompute_budgets();
+  return BC_OK;
+}
+uint32_t bc_plan_max_constant_errors(const bc_plan* p) { return p->max_constant; }
+uint32_t bc_plan_max_sample_errors(const bc_plan* p) { return p->max_sample; }
+uint32_t bc_plan_max_barcode_errors(const bc_plan* p, uint32_t i) {
+  return i < p->max_barcode.size() ? p->max_barcode[i] : 0;
+}
+int bc_plan_set_min_quality(bc_plan* p, float q) {
+  p->min_quality = q;
+  return BC_OK;
+}
+uint32_t bc_plan_quality_threshold(const bc_plan* p, uint32_t run_len) { return p->quality_threshold(run_len); }
+
+uint64_t bc_plan_table_entries(const bc_plan* p) {
+  bc::HostDevPlan h;
+  if (!p->lower(h)) return 0;
+  return h.table_entries;
+}
+
+}  // extern "C"

@@ -1,0 +1,111 @@
+// tests/emu/emu.cpp -- TEST-ONLY host emulation of the lane code in csrc/bc_lane.h.
+//
+// Runs the SAME per-read logic the gfx950 kernel runs (pack -> anchor -> repair -> quality ->
+// barcode lookup), one read at a time on the CPU, so that the bit tricks can be checked against
+// the oracle in this GPU-less container.  It is not part of the product: the shipped library has
+// no CPU path and nothing outside tests/ builds or loads this file.
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../ngs-barcode-count_amd/csrc/bc_lane.h"
+#include "../../ngs-barcode-count_amd/csrc/bc_plan.hpp"
+
+namespace {
+
+struct HostOps {
+  bool any(bool c) const { return c; }
+  uint32_t nearest(const bc::DevGroup& G, uint32_t q1, uint32_t q2, uint32_t qn, uint32_t qx, bool need) const {
+    if (!need) return bc::kFail;
+    bc::Nearest s;
+    bc::nearest_init(s);
+    for (uint32_t j = 0; j < G.n_refs; ++j) {
+      bool ex;
+      const uint32_t d = bc::ref_distance(q1, q2, qn, qx, G.len, G.r1[j], G.r2[j], G.rn[j], G.rlen[j], ex);
+      bc::nearest_add(s, d, j, ex);
+    }
+    return bc::nearest_result(s.key, s.idx, s.count, G.max_err);
+  }
+};
+
+struct EmuPlan {
+  bc::HostDevPlan h;
+  std::vector<std::vector<uint16_t>> dtables;
+};
+
+template <int NW>
+void run(const EmuPlan& E, const uint8_t* seq, const uint8_t* qual, const uint16_t* lens, uint32_t stride,
+         uint32_t read_len, uint64_t n, uint8_t* outcomes, uint64_t* idx) {
+  const uint32_t maxlen = lens ? stride : read_len;
+  const uint32_t nd = (maxlen + 3) / 4;
+  HostOps ops;
+  std::vector<uint32_t> s32((stride + 512) / 4 + 4), q32((stride + 512) / 4 + 4);
+  for (uint64_t i = 0; i < n; ++i) {
+    // place the read at a rotating byte misalignment to exercise the alignbyte path
+    const uint32_t base = (uint32_t)(i & 3);
+    memset(s32.data(), 'A', s32.size() * 4);
+    memset(q32.data(), 'I', q32.size() * 4);
+    memcpy((uint8_t*)s32.data() + base, seq + i * stride, stride);
+    if (qual) memcpy((uint8_t*)q32.data() + base, qual + i * stride, stride);
+    const uint32_t len = lens ? lens[i] : read_len;
+    bc::ReadResult r = bc::process_read<HostOps, NW>(E.h.plan, ops, s32.data(), q32.data(), base, len, nd, true);
+    outcomes[i] = (uint8_t)r.outcome;
+    idx[i] = r.dense_idx;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+void* emu_plan_create(const bc_plan* p) {
+  EmuPlan* E = new EmuPlan();
+  if (!p->lower(E->h)) {
+    delete E;
+    return nullptr;
+  }
+  E->dtables.resize(E->h.plan.n_groups);
+  HostOps ops;
+  for (uint32_t g = 0; g < E->h.plan.n_groups; ++g) {
+    bc::DevGroup& G = E->h.plan.groups[g];
+    bc::HostSet& H = E->h.sets[g];
+    G.r1 = H.r1.data();
+    G.r2 = H.r2.data();
+    G.rn = H.rn.data();
+    G.rlen = H.rlen.data();
+    G.hkeys = H.hkeys.data();
+    G.hvals = H.hvals.data();
+    if (G.mode == bc::kSetDirect) {
+      const uint32_t nq = 1u << (2 * G.len);
+      E->dtables[g].resize(nq);
+      for (uint32_t q = 0; q < nq; ++q) {
+        const uint32_t r = ops.nearest(G, q & bc::lowmask(G.len), q >> G.len, 0, 0, true);
+        E->dtables[g][q] = r == bc::kFail ? bc::kFail16 : (uint16_t)r;
+      }
+      G.dtable = E->dtables[g].data();
+    }
+  }
+  return E;
+}
+
+void emu_plan_destroy(void* e) { delete (EmuPlan*)e; }
+
+uint64_t emu_table_entries(void* e) { return ((EmuPlan*)e)->h.table_entries; }
+int emu_discard_counts(void* e) { return (int)((EmuPlan*)e)->h.plan.discard_counts; }
+
+int emu_process(void* e, const uint8_t* seq, const uint8_t* qual, const uint16_t* lens, uint32_t stride,
+                uint32_t read_len, uint64_t n, uint8_t* outcomes, uint64_t* idx) {
+  const EmuPlan& E = *(EmuPlan*)e;
+  const uint32_t maxlen = lens ? stride : read_len;
+  if (maxlen <= 128)
+    run<4>(E, seq, qual, lens, stride, read_len, n, outcomes, idx);
+  else if (maxlen <= 256)
+    run<8>(E, seq, qual, lens, stride, read_len, n, outcomes, idx);
+  else if (maxlen <= 320)
+    run<10>(E, seq, qual, lens, stride, read_len, n, outcomes, idx);
+  else
+    return -1;
+  return 0;
+}
+}

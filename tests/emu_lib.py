@@ -1,0 +1,70 @@
+"""Builds and binds tests/emu/libbc_emu.so: the host emulation of the kernel's lane code
+(csrc/bc_lane.h) plus the host-only plan code (csrc/bc_plan.cpp).  TEST-ONLY."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "ngs-barcode-count_amd", "csrc")
+SO = os.path.join(ROOT, "tests", "emu", "libbc_emu.so")
+SRCS = [os.path.join(ROOT, "tests", "emu", "emu.cpp"), os.path.join(CSRC, "bc_plan.cpp")]
+DEPS = SRCS + [os.path.join(CSRC, f) for f in ("bc_lane.h", "bc_intrin.h", "bc_device_plan.h", "bc_plan.hpp")]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in DEPS):
+            subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Wno-unknown-pragmas", "-fPIC", "-shared",
+                                   "-o", SO] + SRCS)
+        import ngs_barcode_count_amd as pkg
+        L = C.CDLL(SO)
+        pkg._lib.declare(L, pkg._lib.PLAN_API)
+        L.emu_plan_create.restype = C.c_void_p
+        L.emu_plan_create.argtypes = [C.c_void_p]
+        L.emu_plan_destroy.argtypes = [C.c_void_p]
+        L.emu_table_entries.restype = C.c_uint64
+        L.emu_table_entries.argtypes = [C.c_void_p]
+        L.emu_discard_counts.argtypes = [C.c_void_p]
+        L.emu_process.argtypes = [C.c_void_p] * 4 + [C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def make_plan(case):
+    """Plan (host-only functions, served by the emu library) for a cases.build_case() dict"""
+    import ngs_barcode_count_amd as pkg
+    p = pkg.Plan(case["scheme"], lib=lib())
+    if case.get("samples"):
+        for s, i in case["samples"].items():
+            p.add_sample(s, i)
+    if case.get("counted"):
+        for bi, refs in enumerate(case["counted"]):
+            for r in refs:
+                p.add_counted(bi, r, r)
+    kw = case.get("kwargs", {})
+    p.set_max_errors(kw.get("max_sample"), kw.get("max_barcode"), kw.get("max_constant"))
+    p.set_min_quality(kw.get("min_quality", 0.0))
+    return p
+
+
+def emulate(plan, seq, qual, lens, stride, read_len):
+    L = lib()
+    e = L.emu_plan_create(plan._p)
+    if not e:
+        raise RuntimeError(L.bc_last_error().decode())
+    n = seq.size // stride
+    outc = np.zeros(n, dtype=np.uint8)
+    idx = np.zeros(n, dtype=np.uint64)
+    rc = L.emu_process(e, seq.ctypes.data, qual.ctypes.data if qual is not None else None,
+                       lens.ctypes.data if lens is not None else None, stride, read_len, n, outc.ctypes.data,
+                       idx.ctypes.data)
+    entries = L.emu_table_entries(e)
+    discard = L.emu_discard_counts(e)
+    L.emu_plan_destroy(e)
+    assert rc == 0
+    return outc, idx, entries, discard

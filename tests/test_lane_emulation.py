@@ -1,0 +1,63 @@
+"""The kernel's lane code (csrc/bc_lane.h: bit-plane packing, shifted-vector anchor, bit-sliced
+repair, quality thresholds, table/hash/scan barcode lookup) executed on the host through
+tests/emu and compared read by read with the CPU oracle.  The GPU parity tests
+(tests/test_gpu_parity.py) run the same cases through the real kernel."""
+import numpy as np
+import pytest
+
+import cases
+import emu_lib
+import parity
+import readgen
+
+NO_RANDOM = [c for c in cases.ALL_CASES if c not in ("del_random", "example_files", "example_files_samples")]
+
+
+@pytest.mark.parametrize("name", NO_RANDOM)
+@pytest.mark.parametrize("use_lens", [False, True])
+def test_lane_code_vs_oracle(name, use_lens):
+    c = cases.build_case(name, seed=3 + use_lens, n=500)
+    if not use_lens:
+        # uniform length: truncate / drop so every read has the same length
+        rl = min(len(s) for s, _ in c["reads"])
+        c["reads"] = [(s[:rl], q[:rl]) for s, q in c["reads"]]
+    plan = emu_lib.make_plan(c)
+    seq, qual, lens = readgen.to_arrays(c["reads"])
+    stride = seq.shape[1]
+    outc, idx, entries, discard = emu_lib.emulate(plan, seq.reshape(-1), qual.reshape(-1), lens if use_lens else None,
+                                                  stride, stride)
+    parity.check_per_read(c, plan, outc, idx, discard)
+
+
+def test_long_reads_use_wider_planes():
+    for rl in (150, 250, 300):
+        c = cases.build_case("del_mismatch_quality", seed=rl, n=60)
+        rng = np.random.default_rng(rl)
+        c["reads"] = readgen.gen_reads(rng, c["scheme"], 200, rl, list(c["samples"]), c["counted"], p_sub=0.02,
+                                       p_n=0.004)
+        plan = emu_lib.make_plan(c)
+        seq, qual, lens = readgen.to_arrays(c["reads"])
+        outc, idx, entries, discard = emu_lib.emulate(plan, seq.reshape(-1), qual.reshape(-1), None, rl, rl)
+        parity.check_per_read(c, plan, outc, idx, discard)
+
+
+def test_plan_matches_oracle_scheme_compile():
+    import json, os
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat.json")))
+    import ngs_barcode_count_amd as pkg
+    p = pkg.Plan(kat["scheme"], lib=emu_lib.lib())
+    assert p.format_string == kat["format_string"]
+    assert p.regions_string == kat["regions_string"]
+    assert p.regex_string == kat["regex_string"]
+    assert p.constant_region_length == kat["constant_region_length"]
+    b = kat["budgets"]
+    assert (p.max_constant_errors, p.max_sample_errors, p.max_barcode_errors) == (b["constant"], b["sample"],
+                                                                                  b["barcodes"])
+    for row in kat["quality_thresholds"]:
+        p.set_min_quality(row["min_quality"])
+        for n, T in row["T"].items():
+            assert p.quality_threshold(int(n)) == T
+    for k in kat["max_seq_errors"]:
+        m = pkg.MaxSeqErrors(k["args"][0], k["args"][1], k["args"][2], k["args"][3], k["args"][4], k["args"][5], 0.0,
+                             lib=emu_lib.lib())
+        assert [m.max_constant_errors(), m.max_sample_errors(), m.max_barcode_errors()] == k["expect"]
