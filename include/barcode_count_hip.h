@@ -142,6 +142,11 @@ int bc_engine_finish(bc_engine *e, uint64_t *n_rows);
 int bc_engine_rows(bc_engine *e, uint64_t first, uint64_t n, uint32_t *sample_idx, uint32_t *barcode_idx,
                    uint64_t *count);
 
+/* Debug / parity-test hook: the next submits also write, for read i of the submit, its outcome
+ * (BC_* counter index; BC_MATCHED = passed every test) to d_outcome_u8[i] and its dense table index
+ * to d_index_u64[i].  Both device pointers; NULL switches tracing off. */
+int bc_engine_trace(bc_engine *e, void *d_outcome_u8, void *d_index_u64);
+
 /* HIP-event timing of the match/count kernel on the engine's stream (for the roofline) */
 int bc_engine_timing(bc_engine *e, int enable);
 int bc_engine_kernel_ms(bc_engine *e, double *total_ms, uint64_t *launches);

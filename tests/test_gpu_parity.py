@@ -1,0 +1,146 @@
+"""GPU parity: the HIP engine, called through the C ABI, against the CPU oracle.
+Bit-exact bar: six outcome counters, every per-read outcome, every (sample, tuple, count) row."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import parity
+import readgen
+
+pytestmark = pytest.mark.gpu
+
+KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat.json")))
+NO_RANDOM = [c for c in cases.ALL_CASES if c not in ("del_random", "example_files", "example_files_samples")]
+
+
+def _pkg():
+    import ngs_barcode_count_amd as pkg
+    return pkg
+
+
+def make_plan(case):
+    pkg = _pkg()
+    p = pkg.Plan(case["scheme"])
+    if case.get("samples"):
+        for s, i in case["samples"].items():
+            p.add_sample(s, i)
+    if case.get("counted"):
+        for bi, refs in enumerate(case["counted"]):
+            for r in refs:
+                p.add_counted(bi, r, r)
+    kw = case.get("kwargs", {})
+    p.set_max_errors(kw.get("max_sample"), kw.get("max_barcode"), kw.get("max_constant"))
+    p.set_min_quality(kw.get("min_quality", 0.0))
+    return p
+
+
+def run_device(plan, seq, qual, lens, stride, read_len):
+    """-> (engine, per-read outcomes, per-read dense index)"""
+    import torch
+    pkg = _pkg()
+    n = seq.size // stride
+    dseq = torch.from_numpy(seq.reshape(-1)).cuda()
+    dqual = torch.from_numpy(qual.reshape(-1)).cuda() if qual is not None else None
+    dlens = torch.from_numpy(lens.view(np.int16)).cuda() if lens is not None else None
+    outc = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    idx = torch.zeros(n, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    eng = pkg.Engine(plan, device=0)
+    eng.trace(outc.data_ptr(), idx.data_ptr())
+    eng.submit_device(dseq.data_ptr(), dqual.data_ptr() if dqual is not None else None, n, stride, read_len,
+                      dlens.data_ptr() if dlens is not None else None)
+    eng.sync()
+    return eng, outc.cpu().numpy(), idx.cpu().numpy().astype(np.uint64)
+
+
+@pytest.mark.parametrize("k", KAT["fix_error"], ids=[k["id"] for k in KAT["fix_error"]])
+def test_fix_error_kat_on_device(k):
+    """the reference's fix_error doctest values (src/parse.rs:540-551) + Appendix B, on the GPU"""
+    pkg = _pkg()
+    assert pkg.fix_error(k["query"], k["set"], k["max"]) == k["expect"]
+    assert pkg.fix_error(k["query"], k["set"][::-1], k["max"]) == k["expect"]
+
+
+@pytest.mark.parametrize("name", NO_RANDOM)
+@pytest.mark.parametrize("use_lens", [False, True])
+def test_engine_vs_oracle(name, use_lens):
+    c = cases.build_case(name, seed=11 + use_lens, n=3000)
+    if not use_lens:
+        rl = min(len(s) for s, _ in c["reads"])
+        c["reads"] = [(s[:rl], q[:rl]) for s, q in c["reads"]]
+    plan = make_plan(c)
+    seq, qual, lens = readgen.to_arrays(c["reads"])
+    stride = seq.shape[1]
+    eng, outc, idx = run_device(plan, seq, qual, lens if use_lens else None, stride, stride)
+    discard = (not plan.sample_barcode) and len(plan.samples()) > 0
+    o = parity.check_per_read(c, plan, outc, idx, discard)
+    got = eng.counters()
+    for k, v in o.counters.items():
+        assert got[k] == v, (k, got, o.counters)
+    assert got["total_reads"] == len(c["reads"]) and got["unsupported_reads"] == 0
+    assert eng.result_rows() == o.rows()
+    eng.close()
+
+
+def test_kat_reads_on_device():
+    """Appendix B K1-K7b (anchor, exclusive last window, N-free repair, quality offset after repair)
+    with known sets that contain the KAT captures"""
+    scheme = KAT["scheme"].replace("(8)\nTAGA\n", "")  # the dense path has no random barcode yet
+    for r in KAT["reads"]:
+        c = dict(scheme=scheme, samples={"AAAAAAAAAA": "s"}, counted=[["CAGAGA"], ["ATGAAA"], ["GATAGC"]],
+                 kwargs=dict(min_quality=r["min_quality"]), reads=[(r["seq"], r["qual"])])
+        plan = make_plan(c)
+        seq, qual, lens = readgen.to_arrays(c["reads"])
+        eng, outc, idx = run_device(plan, seq, qual, None, seq.shape[1], seq.shape[1])
+        o = parity.check_per_read(c, plan, outc, idx, False)
+        assert parity.CODE[r["outcome"]] == int(outc[0]), r["id"]
+        eng.close()
+
+
+def test_long_reads_and_odd_strides():
+    for rl, stride in ((150, 152), (250, 251), (300, 304), (75, 77)):
+        c = cases.build_case("del_mismatch_quality", seed=rl, n=10)
+        rng = np.random.default_rng(rl)
+        c["reads"] = readgen.gen_reads(rng, c["scheme"], 700, rl, list(c["samples"]), c["counted"], p_sub=0.02,
+                                       p_n=0.004)
+        plan = make_plan(c)
+        seq, qual, lens = readgen.to_arrays(c["reads"], stride=stride)
+        eng, outc, idx = run_device(plan, seq, qual, None, stride, rl)
+        parity.check_per_read(c, plan, outc, idx, False)
+        eng.close()
+
+
+def test_submit_host_equals_submit_device():
+    pkg = _pkg()
+    c = cases.build_case("del_mismatch_quality", seed=5, n=5000)
+    rl = min(len(s) for s, _ in c["reads"])
+    c["reads"] = [(s[:rl], q[:rl]) for s, q in c["reads"]]
+    plan = make_plan(c)
+    seq, qual, lens = readgen.to_arrays(c["reads"])
+    eng, outc, idx = run_device(plan, seq, qual, None, rl, rl)
+    e2 = pkg.Engine(plan, device=0)
+    e2.submit_host(seq.reshape(-1), qual.reshape(-1), rl, rl)
+    assert e2.counters() == eng.counters()
+    assert e2.result_rows() == eng.result_rows()
+    e2.reset()
+    assert sum(e2.counters().values()) == 0 and e2.result_rows() == []
+    eng.close()
+    e2.close()
+
+
+def test_errors_are_loud():
+    pkg = _pkg()
+    with pytest.raises(pkg.BarcodeCountError):  # raw-key mode is not built yet: refuse, never guess
+        pkg.Engine(pkg.Plan("[8]ACGT{8}"), device=0)
+    p = make_plan(dict(scheme="ACGTACGT{8}TTGG", counted=[["ACGTACGT"]], kwargs=dict(min_quality=10.0)))
+    e = pkg.Engine(p, device=0)
+    import torch
+    d = torch.zeros(1024, dtype=torch.uint8, device="cuda")
+    with pytest.raises(pkg.BarcodeCountError):  # quality filter on, no quality buffer
+        e.submit_device(d.data_ptr(), None, 4, 50, 50)
+    with pytest.raises(pkg.BarcodeCountError):  # no such device
+        pkg.Engine(p, device=99)
+    e.close()
