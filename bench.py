@@ -142,7 +142,7 @@ def main():
         return
 
     six = sum(counters[k] for k in ("matched", "constant_region", "sample_barcode", "barcode", "duplicates", "low_quality"))
-    assert six == n * args.steps == counters["total_reads"], counters
+    assert os.environ.get("BC_ABLATE") or six == n * args.steps == counters["total_reads"], counters
     f_matched = counters["matched"] / max(counters["total_reads"], 1)
     b_alg = workloads.bytes_per_read(w, f_matched)
     avg_ms = kernel_ms / max(launches, 1)

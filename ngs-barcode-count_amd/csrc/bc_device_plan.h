@@ -56,6 +56,7 @@ struct DevPlan {
   uint32_t n_runs;
   uint32_t discard_counts;  // sample file given but no sample group: add_count hits a temporary (info.rs:762-766)
   uint32_t has_fmtn;
+  uint32_t ablate;      // perf-debug only (env BC_ABLATE): bit mask of phases to skip; results are then wrong
   uint32_t n_steps[kClasses];
   // step = shift right by (s & 31); if (s & 0x80) combine the shifted vector into the accumulator
   uint32_t steps[kClasses][kMaxSteps];

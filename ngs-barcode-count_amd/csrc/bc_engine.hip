@@ -109,14 +109,16 @@ __global__ __launch_bounds__(kTPB) void match_count_kernel(const DevPlan* __rest
     const uint64_t goff = first * stride;
     const uint4* g = reinterpret_cast<const uint4*>(seq + goff);
     const uint32_t n16 = tile_bytes >> 4;
-    for (uint32_t i = tid; i < n16; i += kTPB) smem[i] = g[i];
+    if (!(pl.ablate & 0x80u))
+      for (uint32_t i = tid; i < n16; i += kTPB) smem[i] = g[i];
     for (uint32_t i = (n16 << 4) + tid; i < tile_bytes; i += kTPB) s8[i] = seq[goff + i];
     // bytes past the tile that the lane code may read: make them plain bases
     for (uint32_t i = tile_bytes + tid; i < tile_bytes + kSlack; i += kTPB) s8[i] = 'A';
     if (with_qual) {
       const uint4* gq = reinterpret_cast<const uint4*>(qual + goff);
       uint4* sq = reinterpret_cast<uint4*>(q8);
-      for (uint32_t i = tid; i < n16; i += kTPB) sq[i] = gq[i];
+      if (!(pl.ablate & 0x80u))
+        for (uint32_t i = tid; i < n16; i += kTPB) sq[i] = gq[i];
       for (uint32_t i = (n16 << 4) + tid; i < tile_bytes; i += kTPB) q8[i] = qual[goff + i];
       for (uint32_t i = tile_bytes + tid; i < tile_bytes + kSlack; i += kTPB) q8[i] = 'I';
     }
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(kTPB) void match_count_kernel(const DevPlan* __rest
     const unsigned long long m = __ballot(active && r.outcome == k);
     if (lane == 0 && m) atomicAdd(&s_cnt[k], (uint32_t)__popcll(m));
   }
-  if (active && r.outcome == kMatched && !pl.discard_counts) atomicAdd(&table[r.dense_idx], 1u);
+  if (active && r.outcome == kMatched && !pl.discard_counts && !(pl.ablate & 0x4u)) atomicAdd(&table[r.dense_idx], 1u);
   if (trace_outcome && active) {
     trace_outcome[first + tid] = (uint8_t)r.outcome;
     trace_idx[first + tid] = r.dense_idx;
@@ -328,6 +330,7 @@ static int engine_init(bc_engine* e, const bc_plan* p, int device_id, void* hip_
   e->has_sample_group = p->sample_barcode;
 
   DevPlan& P = e->h.plan;
+  if (const char* ab = getenv("BC_ABLATE")) P.ablate = (uint32_t)strtoul(ab, nullptr, 0);
   for (uint32_t g = 0; g < P.n_groups; ++g) {
     DevGroup& G = P.groups[g];
     HostSet& H = e->h.sets[g];

@@ -258,7 +258,13 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
 
   Planes<NW> P;
   uint32_t bad;
-  pack_read<NW>(seq32, base, nd, P, bad);
+  if (pl.ablate & 0x40u) {
+    bad = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { P.p1[w] = base * 2654435761u + w; P.p2[w] = base * 40503u + w; P.pn[w] = 0; P.px[w] = 0; }
+  } else {
+    pack_read<NW>(seq32, base, nd, P, bad);
+  }
   uint32_t inr[NW];
   low_bits<NW>(inr, len);
   bool unsupported = false;
@@ -282,7 +288,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
   low_bits<NW>(acc, len >= L ? len - L + 1u : 0u);  // offsets o with o + L <= len
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    const uint32_t ns = pl.n_steps[c];
+    const uint32_t ns = (pl.ablate & 0x10u) ? 0u : pl.n_steps[c];
     if (ns) {
       uint32_t v[NW];
       eq_vector<NW>(P, inr, c, v);
@@ -328,7 +334,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
 
   // ---- constant-region repair: fix_constant_region (parse.rs:287-313) --------------------------
   bool repaired = false;
-  if (ops.any(active && !found && !unsupported)) {
+  if (!(pl.ablate & 0x1u) && ops.any(active && !found && !unsupported)) {
     // windows 0 .. len-L-1 only: the last window is never tested (parse.rs:291-295)
     uint32_t cand[NW];
     low_bits<NW>(cand, len > L ? len - L : 0u);
@@ -417,7 +423,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
   if (!found) outcome = kConstantRegion;  // parse.rs:145
 
   // ---- quality filter (parse.rs:98-119, 331-375) ------------------------------------------------
-  if (pl.quality_on) {
+  if (pl.quality_on && !(pl.ablate & 0x8u)) {
     // after a repair the quality line is read from offset 0
     const uint32_t qstart = repaired ? 0u : start;
     const uint32_t avail = len - qstart;  // quality line assumed as long as the sequence line
@@ -441,7 +447,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
   shr_lane<NW>(P.pn, start);
   shr_lane<NW>(P.px, start);
   uint64_t didx = 0;
-  for (uint32_t g = 0; g < pl.n_groups; ++g) {
+  for (uint32_t g = 0; g < ((pl.ablate & 0x20u) ? 0u : pl.n_groups); ++g) {
     const DevGroup& G = pl.groups[g];
     if (G.mode == kSetNone) continue;
     const uint32_t q1 = extract_uniform<NW>(P.p1, G.off, G.len);
@@ -482,6 +488,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
     } else {
       need = live;
     }
+    if (pl.ablate & 0x2u) need = false;
     const uint32_t rr = ops.nearest(G, q1, q2, qn, qx, need);
     if (need) r = rr;
     if (live) {
