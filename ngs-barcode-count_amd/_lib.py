@@ -97,7 +97,7 @@ def load(path=None):
     global _lib
     if path is None and _lib is not None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("BC_LIB") or LIB_PATH  # BC_LIB: perf experiments with variant builds
     if not os.path.exists(p):
         raise RuntimeError("HIP engine library not built: %s (run `python -c 'import __graft_entry__ as g; "
                            "g.build()'` or `make -C %s`)" % (p, CSRC_DIR))

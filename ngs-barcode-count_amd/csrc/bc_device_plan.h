@@ -37,7 +37,10 @@ struct DevGroup {
   uint32_t hmask;      // hash slots - 1
   uint32_t has_odd;    // set holds refs with 'N' or of a different length (no single-N shortcut)
   uint64_t table_stride;  // multiplier of this group's index in the dense counter index
-  const uint16_t* dtable; // kSetDirect: fix_error result for every N-free capture, kFail16 = None
+  // kSetDirect: one u32 per N-free capture q1 | q2 << len:
+  //   bits 0-15 fix_error's verdict (reference index, kFail16 = None)
+  //   bits 16-23 distance of the nearest reference (capped at 255), bit 24 set when only one reference is that near
+  const uint32_t* dtable;
   const uint32_t* r1;     // reference bit planes (bit i = base i): ASCII bit 1
   const uint32_t* r2;     //                                          ASCII bit 2
   const uint32_t* rn;     // 'N' positions of the reference
@@ -58,8 +61,9 @@ struct DevPlan {
   uint32_t has_fmtn;
   uint32_t ablate;      // perf-debug only (env BC_ABLATE): bit mask of phases to skip; results are then wrong
   uint32_t n_steps[kClasses];
-  // step = shift right by (s & 31); if (s & 0x80) combine the shifted vector into the accumulator
-  uint32_t steps[kClasses][kMaxSteps];
+  // one byte per step, four steps per dword: shift the vector right by (s & 31); if (s & 0x80)
+  // combine the shifted vector into the accumulator.  One spare dword so a prefetch stays inside.
+  uint32_t steps[kClasses][kMaxSteps / 4 + 1];
   uint32_t run_off[kMaxRuns];   // quality runs in regions_string coordinates
   uint32_t run_len[kMaxRuns];
   uint32_t run_thr[kMaxRuns];   // low <=> sum(scores) < thr   (f32-exact, Appendix A Q10)

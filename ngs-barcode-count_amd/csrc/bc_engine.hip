@@ -21,7 +21,9 @@
 namespace bc {
 
 constexpr int kTPB = 256;          // reads (lanes) per workgroup
-constexpr uint32_t kSlack = 384;   // LDS bytes past the last read that the lane code may touch
+#ifndef BC_MIN_WAVES
+#define BC_MIN_WAVES 1  // occupancy floor (waves per SIMD) the register allocator must honour
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // wave-level pieces
@@ -57,14 +59,55 @@ __device__ __forceinline__ uint32_t wave_fix_error(const DevGroup& G, uint32_t q
   return unique ? nearest_result(kmin, idx, cnt, G.max_err) : kFail;
 }
 
+// Wave-private LDS tile: each wavefront stages the 64 reads it owns (64*stride contiguous bytes of
+// the batch, 16 B per lane and instruction) and never needs a workgroup barrier to use them: LDS
+// executes one wave's instructions in order, so only the compiler has to be told not to reorder.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ void stage_tile(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t bytes,
+                                           uint32_t region, uint8_t pad, uint32_t lane) {
+  const uint4* g = reinterpret_cast<const uint4*>(src);
+  uint4* d = reinterpret_cast<uint4*>(dst);
+  const uint32_t n16 = bytes >> 4;
+  for (uint32_t i0 = 0; i0 < n16; i0 += 256) {  // four independent 1-KiB wave loads in flight
+    const uint32_t ia = i0 + lane, ib = ia + 64u, ic = ia + 128u, id = ia + 192u;
+    const uint32_t last = n16 - 1u;
+    const uint4 ra = g[ia < n16 ? ia : last];
+    const uint4 rb = g[ib < n16 ? ib : last];
+    const uint4 rc = g[ic < n16 ? ic : last];
+    const uint4 rd = g[id < n16 ? id : last];
+    if (ia < n16) d[ia] = ra;
+    if (ib < n16) d[ib] = rb;
+    if (ic < n16) d[ic] = rc;
+    if (id < n16) d[id] = rd;
+  }
+  for (uint32_t i = (n16 << 4) + lane; i < bytes; i += 64) dst[i] = src[i];
+  // bytes past the reads that the lane code may touch: plain values
+  for (uint32_t i = bytes + lane; i < region; i += 64) dst[i] = pad;
+}
+
 struct DeviceOps {
+  uint8_t* tile;          // this wave's LDS region
+  const uint8_t* qsrc;    // this wave's quality lines in global memory
+  uint32_t bytes, region, lane;
+
   __device__ __forceinline__ bool any(bool c) const { return __any(c) != 0; }
+  // the sequence bytes are dead once the planes are built: reuse the tile for the quality lines
+  __device__ __forceinline__ const uint32_t* stage_quality() const {
+    wave_lds_fence();
+    stage_tile(tile, qsrc, bytes, region, (uint8_t)'I', lane);
+    wave_lds_fence();
+    return reinterpret_cast<const uint32_t*>(tile);
+  }
   // every lane calls this; lanes with `need` get their capture resolved one after the other
   __device__ __forceinline__ uint32_t nearest(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t qn, uint32_t qx,
                                               bool need) const {
     unsigned long long todo = __ballot(need);
     uint32_t out = kFail;
-    const uint32_t lane = __lane_id();
     while (todo) {
       const int src = __ffsll(todo) - 1;
       todo &= todo - 1;
@@ -80,15 +123,15 @@ struct DeviceOps {
 };
 
 // ------------------------------------------------------------------------------------------------
-// the hot kernel: SequenceParser::parse for 256 reads per workgroup
+// the hot kernel: SequenceParser::parse, 64 reads per wavefront, 4 wavefronts per workgroup
 // ------------------------------------------------------------------------------------------------
-template <int NW>
-__global__ __launch_bounds__(kTPB) void match_count_kernel(const DevPlan* __restrict__ plp,
+template <int NW, int NWW>
+__global__ __launch_bounds__(kTPB, BC_MIN_WAVES) void match_count_kernel(const DevPlan* __restrict__ plp,
                                                            const uint8_t* __restrict__ seq,
                                                            const uint8_t* __restrict__ qual,
                                                            const uint16_t* __restrict__ lens, uint32_t stride,
                                                            uint32_t read_len, uint32_t nd, uint64_t n_reads,
-                                                           uint32_t tile_alloc, uint32_t* __restrict__ table,
+                                                           uint32_t region, uint32_t* __restrict__ table,
                                                            unsigned long long* __restrict__ counters,
                                                            uint8_t* __restrict__ trace_outcome,
                                                            uint64_t* __restrict__ trace_idx) {
@@ -96,60 +139,64 @@ __global__ __launch_bounds__(kTPB) void match_count_kernel(const DevPlan* __rest
   __shared__ uint32_t s_cnt[BC_NCOUNTERS];
   const DevPlan& pl = *plp;
   const uint32_t tid = threadIdx.x;
-  const uint64_t first = (uint64_t)blockIdx.x * kTPB;
-  const uint64_t left = n_reads - first;
-  const uint32_t n_here = left < (uint64_t)kTPB ? (uint32_t)left : (uint32_t)kTPB;
-  const uint32_t tile_bytes = n_here * stride;
-  uint8_t* s8 = reinterpret_cast<uint8_t*>(smem);
-  uint8_t* q8 = s8 + tile_alloc;
-  const bool with_qual = pl.quality_on != 0;
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = tid >> 6;
+  if (tid < BC_NCOUNTERS) s_cnt[tid] = 0;
 
-  // ---- stage the tile: 16 B per lane, contiguous (first*stride is a multiple of 256 bytes) ----
-  {
-    const uint64_t goff = first * stride;
-    const uint4* g = reinterpret_cast<const uint4*>(seq + goff);
-    const uint32_t n16 = tile_bytes >> 4;
-    if (!(pl.ablate & 0x80u))
-      for (uint32_t i = tid; i < n16; i += kTPB) smem[i] = g[i];
-    for (uint32_t i = (n16 << 4) + tid; i < tile_bytes; i += kTPB) s8[i] = seq[goff + i];
-    // bytes past the tile that the lane code may read: make them plain bases
-    for (uint32_t i = tile_bytes + tid; i < tile_bytes + kSlack; i += kTPB) s8[i] = 'A';
-    if (with_qual) {
-      const uint4* gq = reinterpret_cast<const uint4*>(qual + goff);
-      uint4* sq = reinterpret_cast<uint4*>(q8);
-      if (!(pl.ablate & 0x80u))
-        for (uint32_t i = tid; i < n16; i += kTPB) sq[i] = gq[i];
-      for (uint32_t i = (n16 << 4) + tid; i < tile_bytes; i += kTPB) q8[i] = qual[goff + i];
-      for (uint32_t i = tile_bytes + tid; i < tile_bytes + kSlack; i += kTPB) q8[i] = 'I';
-    }
-    if (tid < BC_NCOUNTERS) s_cnt[tid] = 0;
-  }
-  __syncthreads();
-
-  const bool active = tid < n_here;
-  uint32_t len = 0;
-  if (active) len = lens ? (uint32_t)lens[first + tid] : read_len;
-  const uint32_t base = (active ? tid : 0u) * stride;
   DeviceOps ops;
-  const ReadResult r = process_read<DeviceOps, NW>(pl, ops, reinterpret_cast<const uint32_t*>(s8),
-                                                   reinterpret_cast<const uint32_t*>(q8), base, len, nd, active);
+  ops.tile = reinterpret_cast<uint8_t*>(smem) + wave * region;
+  ops.region = region;
+  ops.lane = lane;
 
-  // ---- outcome counters (SequenceErrors, info.rs:16-139): one LDS add per wave and counter ----
-  const uint32_t lane = __lane_id();
+  // Persistent wavefronts: wave-tile t = 64 consecutive reads; this wave takes tiles
+  // gid, gid + G, gid + 2G, ...  No workgroup barrier inside the loop; the outcome counters stay in
+  // (scalar) registers until the very end, so the six global counters see one add per workgroup.
+  const uint64_t n_tiles = (n_reads + 63u) >> 6;
+  const uint64_t n_waves = (uint64_t)gridDim.x * (kTPB / 64);
+  uint32_t acc_cnt[BC_NCOUNTERS];
 #pragma unroll
-  for (uint32_t k = 0; k < BC_NCOUNTERS; ++k) {
-    if (k == BC_DUPLICATES || k == BC_TOTAL_READS) continue;
-    const unsigned long long m = __ballot(active && r.outcome == k);
-    if (lane == 0 && m) atomicAdd(&s_cnt[k], (uint32_t)__popcll(m));
+  for (int k = 0; k < BC_NCOUNTERS; ++k) acc_cnt[k] = 0;
+  for (uint64_t t = (uint64_t)blockIdx.x * (kTPB / 64) + wave; t < n_tiles; t += n_waves) {
+    const uint64_t wfirst = t << 6;
+    const uint32_t n_w = n_reads - wfirst < 64u ? (uint32_t)(n_reads - wfirst) : 64u;
+    const uint64_t goff = wfirst * stride;  // multiple of 64 bytes: 16-byte aligned
+    ops.qsrc = qual + goff;
+    ops.bytes = n_w * stride;
+    wave_lds_fence();  // the previous tile's last LDS reads are done before the tile is overwritten
+    if (!(pl.ablate & 0x80u)) stage_tile(ops.tile, seq + goff, ops.bytes, region, (uint8_t)'A', lane);
+    wave_lds_fence();
+
+    const bool active = lane < n_w;
+    uint32_t len = 0;
+    if (active) len = lens ? (uint32_t)lens[wfirst + lane] : read_len;
+    const uint32_t base = (active ? lane : 0u) * stride;
+    const ReadResult r =
+        process_read<DeviceOps, NW, NWW>(pl, ops, reinterpret_cast<const uint32_t*>(ops.tile), base, len, nd, active);
+
+    // outcome counters (SequenceErrors, info.rs:16-139)
+#pragma unroll
+    for (uint32_t k = 0; k < BC_NCOUNTERS; ++k) {
+      if (k == BC_DUPLICATES || k == BC_TOTAL_READS) continue;
+      acc_cnt[k] += (uint32_t)__popcll(__ballot(active && r.outcome == k));
+    }
+    acc_cnt[BC_TOTAL_READS] += n_w;
+    // Results::add_count (info.rs:761-767): one no-return atomic into the dense counter table
+    if (active && r.outcome == kMatched && !pl.discard_counts && !(pl.ablate & 0x4u)) atomicAdd(&table[r.dense_idx], 1u);
+    if (trace_outcome && active) {
+      trace_outcome[wfirst + lane] = (uint8_t)r.outcome;
+      trace_idx[wfirst + lane] = r.dense_idx;
+    }
   }
-  if (active && r.outcome == kMatched && !pl.discard_counts && !(pl.ablate & 0x4u)) atomicAdd(&table[r.dense_idx], 1u);
-  if (trace_outcome && active) {
-    trace_outcome[first + tid] = (uint8_t)r.outcome;
-    trace_idx[first + tid] = r.dense_idx;
+
+  __syncthreads();  // s_cnt zeroed
+  if (lane == 0) {
+#pragma unroll
+    for (uint32_t k = 0; k < BC_NCOUNTERS; ++k)
+      if (acc_cnt[k]) atomicAdd(&s_cnt[k], acc_cnt[k]);
   }
   __syncthreads();
   if (tid < BC_NCOUNTERS) {
-    const uint32_t v = tid == BC_TOTAL_READS ? n_here : s_cnt[tid];
+    const uint32_t v = s_cnt[tid];
     if (v) atomicAdd(&counters[tid], (unsigned long long)v);
   }
 }
@@ -157,22 +204,13 @@ __global__ __launch_bounds__(kTPB) void match_count_kernel(const DevPlan* __rest
 // ------------------------------------------------------------------------------------------------
 // plan-time kernels
 // ------------------------------------------------------------------------------------------------
-// correction table of a short barcode: the verdict of fix_error for every N-free capture
-__global__ void build_dtable_kernel(const DevPlan* __restrict__ plp, uint32_t g, uint16_t* __restrict__ out) {
+// correction table of a short barcode: fix_error's verdict for every N-free capture
+__global__ void build_dtable_kernel(const DevPlan* __restrict__ plp, uint32_t g, uint32_t* __restrict__ out) {
   const DevGroup& G = plp->groups[g];
   const uint32_t nq = 1u << (2 * G.len);
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nq) return;
-  const uint32_t q1 = q & lowmask(G.len), q2 = q >> G.len;
-  Nearest s;
-  nearest_init(s);
-  for (uint32_t j = 0; j < G.n_refs; ++j) {
-    bool ex;
-    const uint32_t d = ref_distance(q1, q2, 0u, 0u, G.len, G.r1[j], G.r2[j], G.rn[j], G.rlen[j], ex);
-    nearest_add(s, d, j, ex);
-  }
-  const uint32_t r = nearest_result(s.key, s.idx, s.count, G.max_err);
-  out[q] = r == kFail ? kFail16 : (uint16_t)r;
+  out[q] = dtable_entry(G, q);
 }
 
 // bc_fix_error: one wavefront, one query, plain fix_error semantics (no exact-member shortcut)
@@ -272,6 +310,7 @@ struct bc_engine {
   hipEvent_t consumed[kStages] = {nullptr, nullptr};
   size_t stage_bytes = 0;
   uint32_t lds_limit = 0;
+  uint32_t n_cus = 0;
 };
 
 static int upload(bc_engine* e, const void* src, size_t bytes, void** out) {
@@ -326,6 +365,7 @@ static int engine_init(bc_engine* e, const bc_plan* p, int device_id, void* hip_
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device_id));
   e->lds_limit = (uint32_t)prop.maxSharedMemoryPerMultiProcessor;
+  e->n_cus = (uint32_t)prop.multiProcessorCount;
   e->barcode_num = p->barcode_num;
   e->has_sample_group = p->sample_barcode;
 
@@ -346,9 +386,9 @@ static int engine_init(bc_engine* e, const bc_plan* p, int device_id, void* hip_
     }
     if (G.mode == kSetDirect) {
       void* d = nullptr;
-      HIP_TRY(hipMalloc(&d, (size_t)2 << (2 * G.len)));
+      HIP_TRY(hipMalloc(&d, (size_t)4 << (2 * G.len)));
       e->allocs.push_back(d);
-      G.dtable = (const uint16_t*)d;
+      G.dtable = (const uint32_t*)d;
     }
   }
   HIP_TRY(hipMalloc((void**)&e->d_plan, sizeof(DevPlan)));
@@ -358,7 +398,7 @@ static int engine_init(bc_engine* e, const bc_plan* p, int device_id, void* hip_
     if (G.mode != kSetDirect) continue;
     const uint32_t nq = 1u << (2 * G.len);
     hipLaunchKernelGGL(build_dtable_kernel, dim3((nq + 255) / 256), dim3(256), 0, e->stream, e->d_plan, g,
-                       const_cast<uint16_t*>(G.dtable));
+                       const_cast<uint32_t*>(G.dtable));
     HIP_TRY(hipGetLastError());
   }
   e->table_entries = e->h.table_entries;
@@ -375,22 +415,26 @@ static int engine_init(bc_engine* e, const bc_plan* p, int device_id, void* hip_
   return BC_OK;
 }
 
-template <int NW>
+template <int NW, int NWW>
 static int launch_match(bc_engine* e, const void* d_seq, const void* d_qual, const void* d_lens, uint32_t stride,
                         uint32_t read_len, uint32_t nd, uint64_t n_reads, uint64_t trace_off) {
-  const uint32_t tile_alloc = (kTPB * stride + kSlack + 15u) & ~15u;
-  const uint32_t lds = tile_alloc * (e->h.plan.quality_on ? 2u : 1u);
+  // per-wave LDS region: 64 reads + the few bytes past them the lane code may touch
+  const uint32_t L = e->h.plan.L;
+  const uint32_t slack = (uint32_t)NW * 32u + 16u + (L > stride ? L - stride : 0u);
+  const uint32_t tile_alloc = (64u * stride + slack + 15u) & ~15u;
+  const uint32_t lds = tile_alloc * (kTPB / 64);
   if (lds + 64 > e->lds_limit) {
     set_error("read stride too large for one LDS tile");
     return BC_ERR_UNSUPPORTED;
   }
-  auto kern = match_count_kernel<NW>;
+  auto kern = match_count_kernel<NW, NWW>;
   if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const uint64_t blocks = (n_reads + kTPB - 1) / kTPB;
-  if (blocks > 0x7FFFFFFFull) {
-    set_error("batch too large: at most 2^31 * 256 reads per submit");
-    return BC_ERR_INVALID;
-  }
+  // persistent grid: as many workgroups as the chip holds at once (or fewer for a small batch)
+  int per_cu = 0;
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, kTPB, lds));
+  if (per_cu < 1) per_cu = 1;
+  const uint64_t resident = (uint64_t)per_cu * e->n_cus;
+  const uint64_t blocks = std::min<uint64_t>((n_reads + kTPB - 1) / kTPB, resident);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (e->timing) {
     HIP_TRY(hipEventCreate(&e0));
@@ -431,9 +475,25 @@ static int submit_device_impl(bc_engine* e, const void* d_seq, const void* d_qua
   }
   const uint32_t nd = (maxlen + 3) / 4;
   HIP_TRY(hipSetDevice(e->device));
-  if (maxlen <= 128) return launch_match<4>(e, d_seq, d_qual, d_lens, stride, read_len, nd, n_reads, trace_off);
-  if (maxlen <= 256) return launch_match<8>(e, d_seq, d_qual, d_lens, stride, read_len, nd, n_reads, trace_off);
-  if (maxlen <= 320) return launch_match<10>(e, d_seq, d_qual, d_lens, stride, read_len, nd, n_reads, trace_off);
+  // candidate offsets 0 .. maxlen-L: how many 32-bit words the anchor / repair vectors need
+  const uint32_t L = e->h.plan.L;
+  const uint32_t nww = maxlen >= L ? (maxlen - L + 1 + 31) / 32 : 1;
+#define BC_LAUNCH(NW_, NWW_) return launch_match<NW_, NWW_>(e, d_seq, d_qual, d_lens, stride, read_len, nd, n_reads, trace_off)
+  if (maxlen <= 128) {
+    if (nww <= 1) BC_LAUNCH(4, 1);
+    if (nww <= 2) BC_LAUNCH(4, 2);
+    BC_LAUNCH(4, 4);
+  }
+  if (maxlen <= 256) {
+    if (nww <= 2) BC_LAUNCH(8, 2);
+    if (nww <= 4) BC_LAUNCH(8, 4);
+    BC_LAUNCH(8, 8);
+  }
+  if (maxlen <= 320) {
+    if (nww <= 4) BC_LAUNCH(10, 4);
+    BC_LAUNCH(10, 10);
+  }
+#undef BC_LAUNCH
   set_error("submit: reads longer than 320 bases are not supported");
   return BC_ERR_UNSUPPORTED;
 }

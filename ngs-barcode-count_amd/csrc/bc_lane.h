@@ -39,8 +39,11 @@ BC_HD uint64_t hash64(uint64_t x) {
 template <int NW>
 BC_HD void pack_read(const uint32_t* t32, uint32_t base, uint32_t nd, Planes<NW>& P, uint32_t& bad) {
   const uint32_t a = base & 3u;
-  const uint32_t k0 = base >> 2;
-  uint32_t prev = t32[k0];
+  const uint32_t* src = t32 + (base >> 2);
+  // every LDS read is issued before the first use: the conversion never waits on one load at a time
+  uint32_t raw[NW * 8 + 1];
+#pragma unroll
+  for (int i = 0; i <= NW * 8; ++i) raw[i] = src[i];
   bad = 0;
 #pragma unroll
   for (int w = 0; w < NW; ++w) {
@@ -48,13 +51,11 @@ BC_HD void pack_read(const uint32_t* t32, uint32_t base, uint32_t nd, Planes<NW>
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
       uint32_t a1 = 0, a2 = 0, an = 0;
+      if ((uint32_t)(w * 8 + h * 2) < nd) {  // wave-uniform, per 8 bases
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const uint32_t idx = (uint32_t)(w * 8 + h * 2 + j);
-        if (idx < nd) {  // wave-uniform
-          const uint32_t nxt = t32[k0 + idx + 1];
-          const uint32_t d = alignbyte(nxt, prev, a);
-          prev = nxt;
+        for (int j = 0; j < 2; ++j) {
+          const int idx = w * 8 + h * 2 + j;
+          const uint32_t d = alignbyte(raw[idx + 1], raw[idx], a);
           const uint32_t wt = j ? 0x80402010u : 0x08040201u;
           a1 = udot4(d & 0x02020202u, wt, a1);
           a2 = udot4(d & 0x04040404u, wt, a2);
@@ -79,8 +80,8 @@ BC_HD void pack_read(const uint32_t* t32, uint32_t base, uint32_t nd, Planes<NW>
 template <int NW>
 BC_HD void pack_exact(const uint32_t* t32, uint32_t base, uint32_t nd, Planes<NW>& P, uint32_t (&hi)[NW]) {
   const uint32_t a = base & 3u;
-  const uint32_t k0 = base >> 2;
-  uint32_t prev = t32[k0];
+  const uint32_t* src = t32 + (base >> 2);
+  uint32_t prev = src[0];
 #pragma unroll
   for (int w = 0; w < NW; ++w) {
     uint32_t ov = 0, on = 0, oh = 0;
@@ -89,11 +90,11 @@ BC_HD void pack_exact(const uint32_t* t32, uint32_t base, uint32_t nd, Planes<NW
       uint32_t av = 0, an = 0, ah = 0;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const uint32_t idx = (uint32_t)(w * 8 + h * 2 + j);
-        if (idx < nd) {
-          const uint32_t nxt = t32[k0 + idx + 1];
-          const uint32_t d = alignbyte(nxt, prev, a);
-          prev = nxt;
+        const int idx = w * 8 + h * 2 + j;
+        const uint32_t nxt = src[idx + 1];
+        const uint32_t d = alignbyte(nxt, prev, a);
+        prev = nxt;
+        if ((uint32_t)(w * 8 + h * 2) < nd) {
           const uint32_t wt = j ? 0x80402010u : 0x08040201u;
           const uint32_t ex = perm(0u, 0x47544341u, (d >> 1) & 0x03030303u);
           av = udot4(zero_bytes(d ^ ex) >> 7, wt, av);
@@ -179,6 +180,29 @@ BC_HD void eq_vector(const Planes<NW>& P, const uint32_t (&inr)[NW], int c, uint
   }
 }
 
+// Runs the shift/apply program of one position class over the vector v (bc_device_plan.h).
+// Steps are packed four to a dword and the next dword is fetched while the current one is being
+// executed, so the scalar loads stay off the critical path.
+template <int NW, class F>
+BC_HD void run_steps(const DevPlan& pl, int c, uint32_t (&v)[NW], F&& apply) {
+  const uint32_t ns = pl.n_steps[c];
+  if (ns == 0) return;
+  const uint32_t* sp = pl.steps[c];
+  uint32_t cur = sp[0];
+  for (uint32_t s0 = 0; s0 < ns; s0 += 4) {
+    const uint32_t nxt = sp[(s0 >> 2) + 1];  // one dword past the program is still inside the array
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (s0 + t < ns) {
+        const uint32_t st = (cur >> (8 * t)) & 0xFFu;
+        shr_uniform<NW>(v, st & 31u);
+        if (st & 0x80u) apply(v);
+      }
+    }
+    cur = nxt;
+  }
+}
+
 // ---- quality (RawSequenceRead::low_quality, parse.rs:331-375) ----------------------------------
 // sum of (byte - 33) mod 256 over `len` bytes starting at byte address `addr` of the quality tile
 BC_HD uint32_t score_sum(const uint32_t* q32, uint32_t addr, uint32_t len) {
@@ -240,6 +264,120 @@ BC_HD uint32_t nearest_result(uint32_t key, uint32_t idx, uint32_t count, uint32
   return (count == 1u && (key == 0u || key - 1u <= max_err)) ? idx : kFail;
 }
 
+// one entry of a kSetDirect correction table (layout: bc_device_plan.h)
+BC_HD uint32_t dtable_entry(const DevGroup& G, uint32_t q) {
+  const uint32_t q1 = q & lowmask(G.len), q2 = q >> G.len;
+  Nearest s;
+  nearest_init(s);
+  for (uint32_t j = 0; j < G.n_refs; ++j) {
+    bool ex;
+    const uint32_t d = ref_distance(q1, q2, 0u, 0u, G.len, G.r1[j], G.r2[j], G.rn[j], G.rlen[j], ex);
+    nearest_add(s, d, j, ex);
+  }
+  const uint32_t r = nearest_result(s.key, s.idx, s.count, G.max_err);
+  uint32_t dmin = s.key == 0u ? 0u : s.key - 1u;
+  if (dmin > 255u) dmin = 255u;
+  return (r == kFail ? (uint32_t)kFail16 : r) | (dmin << 16) | ((s.count == 1u ? 1u : 0u) << 24);
+}
+
+// A capture with exactly one 'N' (and nothing else unusual) against a set of plain, equal-length
+// references: 'N' is free (parse.rs:569), so its distance to a reference r is the distance of
+// the capture with N replaced by r's base there.  Hence the nearest references of the capture are
+// the nearest references of its four substitutions at the smallest of their four minimum
+// distances D; the match is unique iff exactly one substitution reaches D and does so uniquely.
+BC_HD uint32_t single_n_lookup(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t qn) {
+  const uint32_t k = ctz(qn);
+  const uint32_t b1 = q1 & ~qn, b2 = q2 & ~qn;
+  uint32_t best = 256u, res = kFail;
+  bool ok = false;
+#pragma unroll
+  for (uint32_t b = 0; b < 4; ++b) {
+    const uint32_t t = G.dtable[(b1 | ((b & 1u) << k)) | ((b2 | ((b >> 1) << k)) << G.len)];
+    const uint32_t d = (t >> 16) & 0xFFu;
+    if (d < best) {
+      best = d;
+      ok = ((t >> 24) & 1u) != 0u;
+      res = t & 0xFFFFu;
+    } else if (d == best) {
+      ok = false;
+    }
+  }
+  return (ok && best <= G.max_err && res != (uint32_t)kFail16) ? res : kFail;
+}
+
+// Constant-region repair for every window of one read at once (fix_constant_region,
+// parse.rs:287-313): the mismatch count of window i is accumulated in NB bit-sliced counter bits
+// (counts above 2^NB-1 go to an overflow mask), then the unique minimum is searched bit by bit.
+// Returns true and the window index when exactly one window has the smallest count and that
+// count is within the budget (fix_error, parse.rs:577-592).
+template <int NW, int NWW, int NB>
+BC_HD bool repair_search(const DevPlan& pl, const Planes<NW>& P, const uint32_t (&inr)[NW], uint32_t len, uint32_t& pos) {
+  const uint32_t L = pl.L;
+  // windows 0 .. len-L-1 only: the last window is never tested (parse.rs:291-295)
+  uint32_t cand[NWW];
+  low_bits<NWW>(cand, len > L ? len - L : 0u);
+  uint32_t cnt[NB][NWW];
+  uint32_t ovf[NWW];
+#pragma unroll
+  for (int w = 0; w < NWW; ++w) {
+    ovf[w] = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) cnt[b][w] = 0;
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (pl.n_steps[c]) {
+      uint32_t v[NW];
+      eq_vector<NW>(P, inr, c, v);
+      // mismatch = differs and neither side is 'N' (parse.rs:569); format 'N's are not in the program
+#pragma unroll
+      for (int w = 0; w < NW; ++w) v[w] = inr[w] & ~P.pn[w] & ~v[w];
+      run_steps<NW>(pl, c, v, [&](const uint32_t (&x)[NW]) {
+#pragma unroll
+        for (int w = 0; w < NWW; ++w) {
+          uint32_t carry = x[w];
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            const uint32_t t = cnt[b][w] & carry;
+            cnt[b][w] ^= carry;
+            carry = t;
+          }
+          ovf[w] |= carry;
+        }
+      });
+    }
+  }
+#pragma unroll
+  for (int w = 0; w < NWW; ++w) cand[w] &= ~ovf[w];
+#pragma unroll
+  for (int b = NB - 1; b >= 0; --b) {
+    uint32_t t[NWW];
+    uint32_t nz = 0;
+#pragma unroll
+    for (int w = 0; w < NWW; ++w) {
+      t[w] = cand[w] & ~cnt[b][w];
+      nz |= t[w];
+    }
+#pragma unroll
+    for (int w = 0; w < NWW; ++w) cand[w] = nz ? t[w] : cand[w];
+  }
+  uint32_t n_min = 0, val = 0;
+  pos = 0;
+#pragma unroll
+  for (int w = NWW - 1; w >= 0; --w) {
+    n_min += popc(cand[w]);
+    if (cand[w]) pos = 32u * (uint32_t)w + ctz(cand[w]);
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int w = 0; w < NWW; ++w) o |= cand[w] & cnt[b][w];
+    val |= (o ? 1u : 0u) << b;
+  }
+  return n_min == 1u && val <= pl.max_const;
+}
+
 // ---- the per-read decision tree ---------------------------------------------------------------
 struct ReadResult {
   uint32_t outcome;    // Outcome; kMatched means "passed every test" (duplicate detection is later)
@@ -249,9 +387,13 @@ struct ReadResult {
 // Ops must provide:
 //   bool any(bool)                               -- wave vote
 //   uint32_t nearest(const DevGroup&, q1,q2,qn,qx, bool need) -- cooperative Hamming search, every lane calls it
-template <class Ops, int NW>
-BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32, const uint32_t* qual32, uint32_t base,
-                              uint32_t len, uint32_t nd, bool active) {
+//   const uint32_t* stage_quality()              -- called once, by every lane, after the last use of the
+//                                                   sequence bytes: returns where the quality lines are
+//                                                   (the GPU reloads the wave's LDS tile with them)
+// NW = 32-base words per read; NWW = words of candidate offsets / repair windows (len - L + 1 <= 32*NWW)
+template <class Ops, int NW, int NWW>
+BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32, uint32_t base, uint32_t len,
+                              uint32_t nd, bool active) {
   ReadResult res;
   res.outcome = kMatched;
   res.dense_idx = 0;
@@ -268,7 +410,8 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
   uint32_t inr[NW];
   low_bits<NW>(inr, len);
   bool unsupported = false;
-  if (ops.any(active && bad != 0u)) {
+  const bool anyx = ops.any(active && bad != 0u);
+  if (anyx) {
     uint32_t hi[NW];
     pack_exact<NW>(seq32, base, nd, P, hi);
     uint32_t h = 0;
@@ -284,48 +427,40 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
 
   const uint32_t L = pl.L;
   // ---- leftmost exact anchor: Regex::is_match / captures (parse.rs:92-95, 153-156) -------------
-  uint32_t acc[NW];
-  low_bits<NW>(acc, len >= L ? len - L + 1u : 0u);  // offsets o with o + L <= len
+  uint32_t acc[NWW];
+  low_bits<NWW>(acc, len >= L ? len - L + 1u : 0u);  // offsets o with o + L <= len
+  if (!(pl.ablate & 0x10u)) {
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const uint32_t ns = (pl.ablate & 0x10u) ? 0u : pl.n_steps[c];
-    if (ns) {
-      uint32_t v[NW];
-      eq_vector<NW>(P, inr, c, v);
-      for (uint32_t s = 0; s < ns; ++s) {
-        const uint32_t st = pl.steps[c][s];
-        shr_uniform<NW>(v, st & 31u);
-        if (st & 0x80u) {
+    for (int c = 0; c < 4; ++c) {
+      if (pl.n_steps[c]) {
+        uint32_t v[NW];
+        eq_vector<NW>(P, inr, c, v);
+        run_steps<NW>(pl, c, v, [&](const uint32_t (&x)[NW]) {
 #pragma unroll
-          for (int w = 0; w < NW; ++w) acc[w] &= v[w];
-        }
+          for (int w = 0; w < NWW; ++w) acc[w] &= x[w];
+        });
       }
     }
   }
   // scheme 'N' positions must be one of A,G,C,T ([AGCT]{n}, info.rs:291-294)
-  uint32_t fnok[NW];
+  uint32_t fnok[NWW];
 #pragma unroll
-  for (int w = 0; w < NW; ++w) fnok[w] = 0xFFFFFFFFu;
+  for (int w = 0; w < NWW; ++w) fnok[w] = 0xFFFFFFFFu;
   if (pl.has_fmtn) {
     uint32_t v[NW];
 #pragma unroll
     for (int w = 0; w < NW; ++w) v[w] = inr[w] & ~(P.pn[w] | P.px[w]);
-    const uint32_t ns = pl.n_steps[kClassFmtN];
-    for (uint32_t s = 0; s < ns; ++s) {
-      const uint32_t st = pl.steps[kClassFmtN][s];
-      shr_uniform<NW>(v, st & 31u);
-      if (st & 0x80u) {
+    run_steps<NW>(pl, kClassFmtN, v, [&](const uint32_t (&x)[NW]) {
 #pragma unroll
-        for (int w = 0; w < NW; ++w) fnok[w] &= v[w];
-      }
-    }
+      for (int w = 0; w < NWW; ++w) fnok[w] &= x[w];
+    });
 #pragma unroll
-    for (int w = 0; w < NW; ++w) acc[w] &= fnok[w];
+    for (int w = 0; w < NWW; ++w) acc[w] &= fnok[w];
   }
   uint32_t start = 0;
   bool found = false;
 #pragma unroll
-  for (int w = NW - 1; w >= 0; --w) {
+  for (int w = NWW - 1; w >= 0; --w) {
     if (acc[w]) {
       start = 32u * (uint32_t)w + ctz(acc[w]);
       found = true;
@@ -335,83 +470,21 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
   // ---- constant-region repair: fix_constant_region (parse.rs:287-313) --------------------------
   bool repaired = false;
   if (!(pl.ablate & 0x1u) && ops.any(active && !found && !unsupported)) {
-    // windows 0 .. len-L-1 only: the last window is never tested (parse.rs:291-295)
-    uint32_t cand[NW];
-    low_bits<NW>(cand, len > L ? len - L : 0u);
-    uint32_t cnt[5][NW];
-    uint32_t ovf[NW];
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      ovf[w] = 0;
-#pragma unroll
-      for (int b = 0; b < 5; ++b) cnt[b][w] = 0;
-    }
-    const uint32_t nb = pl.nb;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const uint32_t ns = pl.n_steps[c];
-      if (ns) {
-        uint32_t v[NW];
-        eq_vector<NW>(P, inr, c, v);
-        // mismatch = differs and neither side is 'N' (parse.rs:569); format 'N's are not in the program
-#pragma unroll
-        for (int w = 0; w < NW; ++w) v[w] = inr[w] & ~P.pn[w] & ~v[w];
-        for (uint32_t s = 0; s < ns; ++s) {
-          const uint32_t st = pl.steps[c][s];
-          shr_uniform<NW>(v, st & 31u);
-          if (st & 0x80u) {
-#pragma unroll
-            for (int w = 0; w < NW; ++w) {
-              uint32_t carry = v[w];
-#pragma unroll
-              for (int b = 0; b < 5; ++b) {
-                if ((uint32_t)b < nb) {
-                  const uint32_t t = cnt[b][w] & carry;
-                  cnt[b][w] ^= carry;
-                  carry = t;
-                }
-              }
-              ovf[w] |= carry;
-            }
-          }
-        }
-      }
-    }
-    // unique minimum over the candidate windows (fix_error, parse.rs:577-592)
-#pragma unroll
-    for (int w = 0; w < NW; ++w) cand[w] &= ~ovf[w];
-#pragma unroll
-    for (int b = 4; b >= 0; --b) {
-      if ((uint32_t)b < nb) {
-        uint32_t t[NW];
-        uint32_t nz = 0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-          t[w] = cand[w] & ~cnt[b][w];
-          nz |= t[w];
-        }
-#pragma unroll
-        for (int w = 0; w < NW; ++w) cand[w] = nz ? t[w] : cand[w];
-      }
-    }
-    uint32_t n_min = 0, val = 0, pos = 0;
-#pragma unroll
-    for (int w = NW - 1; w >= 0; --w) {
-      n_min += popc(cand[w]);
-      if (cand[w]) pos = 32u * (uint32_t)w + ctz(cand[w]);
-    }
-#pragma unroll
-    for (int b = 0; b < 5; ++b) {
-      uint32_t o = 0;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) o |= cand[w] & cnt[b][w];
-      val |= (o ? 1u : 0u) << b;
-    }
-    if (!found && n_min == 1u && val <= pl.max_const) {
+    // counter width is a compile-time constant (a runtime width costs three selects per bit):
+    // any width whose range covers max_const gives the same verdicts
+    uint32_t pos = 0;
+    bool ok;
+    if (pl.nb <= 2u)
+      ok = repair_search<NW, NWW, 2>(pl, P, inr, len, pos);
+    else if (pl.nb == 3u)
+      ok = repair_search<NW, NWW, 3>(pl, P, inr, len, pos);
+    else
+      ok = repair_search<NW, NWW, 5>(pl, P, inr, len, pos);
+    if (!found && ok) {
       // the window replaces the read, constants overwritten by the format
       // (insert_barcodes_constant_region, parse.rs:270-283); the regex then has to match it
       // at offset 0, which only the scheme-N positions can still prevent
-      if (test_bit<NW>(fnok, pos)) {
+      if (test_bit<NWW>(fnok, pos)) {
         found = true;
         repaired = true;
         start = pos;
@@ -424,6 +497,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
 
   // ---- quality filter (parse.rs:98-119, 331-375) ------------------------------------------------
   if (pl.quality_on && !(pl.ablate & 0x8u)) {
+    const uint32_t* qual32 = ops.stage_quality();
     // after a repair the quality line is read from offset 0
     const uint32_t qstart = repaired ? 0u : start;
     const uint32_t avail = len - qstart;  // quality line assumed as long as the sequence line
@@ -445,57 +519,79 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
   shr_lane<NW>(P.p1, start);
   shr_lane<NW>(P.p2, start);
   shr_lane<NW>(P.pn, start);
-  shr_lane<NW>(P.px, start);
+  if (anyx) shr_lane<NW>(P.px, start);
   uint64_t didx = 0;
-  for (uint32_t g = 0; g < ((pl.ablate & 0x20u) ? 0u : pl.n_groups); ++g) {
-    const DevGroup& G = pl.groups[g];
-    if (G.mode == kSetNone) continue;
-    const uint32_t q1 = extract_uniform<NW>(P.p1, G.off, G.len);
-    const uint32_t q2 = extract_uniform<NW>(P.p2, G.off, G.len);
-    const uint32_t qn = extract_uniform<NW>(P.pn, G.off, G.len);
-    const uint32_t qx = extract_uniform<NW>(P.px, G.off, G.len);
-    const bool live = active && outcome == kMatched;
-    const bool clean = (qn | qx) == 0u;
-    uint32_t r = kFail;
-    bool need = false;
-    if (G.mode == kSetDirect) {
-      if (live) {
-        if (clean) {
-          const uint32_t t = G.dtable[q1 | (q2 << G.len)];
-          r = t == kFail16 ? kFail : t;
-        } else {
-          need = true;
-        }
-      }
-    } else if (G.mode == kSetHash) {
-      if (live) {
-        need = true;
-        if (clean) {
-          const uint64_t key = (uint64_t)q1 | ((uint64_t)q2 << 32);
-          uint32_t h = (uint32_t)hash64(key) & G.hmask;
-          for (;;) {
-            const uint32_t v = G.hvals[h];
-            if (v == kFail) break;
-            if (G.hkeys[h] == key) {
-              r = v;
-              need = false;
-              break;
+  const bool pre_ok = active && outcome == kMatched;
+  const uint32_t ng = (pl.ablate & 0x20u) ? 0u : pl.n_groups;
+  // four groups at a time: first every capture is cut out and its table gather issued, then the
+  // verdicts are consumed in order -- the gathers of one read overlap instead of queueing up
+  for (uint32_t g0 = 0; g0 < ng; g0 += 4) {
+    uint32_t q1[4], q2[4], qn[4], qx[4], r[4];
+    bool need[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      r[u] = kFail;
+      need[u] = false;
+      q1[u] = q2[u] = qn[u] = qx[u] = 0;
+      if (g0 + u < ng) {  // wave-uniform
+        const DevGroup& G = pl.groups[g0 + u];
+        if (G.mode != kSetNone) {
+          q1[u] = extract_uniform<NW>(P.p1, G.off, G.len);
+          q2[u] = extract_uniform<NW>(P.p2, G.off, G.len);
+          qn[u] = extract_uniform<NW>(P.pn, G.off, G.len);
+          if (anyx) qx[u] = extract_uniform<NW>(P.px, G.off, G.len);
+          const bool clean = (qn[u] | qx[u]) == 0u;
+          if (pre_ok) {
+            if (G.mode == kSetDirect) {
+              if (clean) {
+                const uint32_t t = G.dtable[q1[u] | (q2[u] << G.len)] & 0xFFFFu;
+                r[u] = t == (uint32_t)kFail16 ? kFail : t;
+              } else if (qx[u] == 0u && !G.has_odd && (qn[u] & (qn[u] - 1u)) == 0u && !(pl.ablate & 0x100u)) {
+                r[u] = single_n_lookup(G, q1[u], q2[u], qn[u]);
+              } else {
+                need[u] = true;
+              }
+            } else if (G.mode == kSetHash) {
+              need[u] = true;
+              if (clean) {
+                const uint64_t key = (uint64_t)q1[u] | ((uint64_t)q2[u] << 32);
+                uint32_t h = (uint32_t)hash64(key) & G.hmask;
+                for (;;) {
+                  const uint32_t v = G.hvals[h];
+                  if (v == kFail) break;
+                  if (G.hkeys[h] == key) {
+                    r[u] = v;
+                    need[u] = false;
+                    break;
+                  }
+                  h = (h + 1u) & G.hmask;
+                }
+              }
+            } else {
+              need[u] = true;
             }
-            h = (h + 1u) & G.hmask;
           }
         }
       }
-    } else {
-      need = live;
     }
-    if (pl.ablate & 0x2u) need = false;
-    const uint32_t rr = ops.nearest(G, q1, q2, qn, qx, need);
-    if (need) r = rr;
-    if (live) {
-      if (r == kFail)
-        outcome = (G.type == kGroupSample) ? kSampleBarcode : kBarcode;  // parse.rs:132-140
-      else
-        didx += (uint64_t)r * G.table_stride;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (g0 + u < ng) {
+        const DevGroup& G = pl.groups[g0 + u];
+        if (G.mode != kSetNone) {
+          // a read that already failed an earlier group is not searched again (parse.rs:481, 500)
+          bool nd_ = need[u] && outcome == kMatched;
+          if (pl.ablate & 0x2u) nd_ = false;
+          const uint32_t rr = ops.nearest(G, q1[u], q2[u], qn[u], qx[u], nd_);
+          if (nd_) r[u] = rr;
+          if (pre_ok && outcome == kMatched) {
+            if (r[u] == kFail)
+              outcome = (G.type == kGroupSample) ? kSampleBarcode : kBarcode;  // parse.rs:132-140
+            else
+              didx += (uint64_t)r[u] * G.table_stride;
+          }
+        }
+      }
     }
   }
   if (unsupported) outcome = kUnsupported;

@@ -185,16 +185,19 @@ bool bc_plan::lower(HostDevPlan& out) const {
     uint32_t cur = 0, n = 0;
     for (uint32_t p : where[c]) {
       uint32_t delta = p - cur;
-      while (delta > 31) {
-        if (n >= (uint32_t)kMaxSteps) break;
-        P.steps[c][n++] = 31;
+      auto put = [&](uint32_t st) {
+        P.steps[c][n >> 2] |= st << (8 * (n & 3));
+        ++n;
+      };
+      while (delta > 31 && n < (uint32_t)kMaxSteps) {
+        put(31);
         delta -= 31;
       }
       if (n >= (uint32_t)kMaxSteps) {
         set_error("unsupported scheme: too many constant positions");
         return false;
       }
-      P.steps[c][n++] = delta | 0x80u;
+      put(delta | 0x80u);
       cur = p;
     }
     P.n_steps[c] = n;

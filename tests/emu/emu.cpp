@@ -15,6 +15,8 @@
 namespace {
 
 struct HostOps {
+  const uint32_t* qual32 = nullptr;
+  const uint32_t* stage_quality() const { return qual32; }
   bool any(bool c) const { return c; }
   uint32_t nearest(const bc::DevGroup& G, uint32_t q1, uint32_t q2, uint32_t qn, uint32_t qx, bool need) const {
     if (!need) return bc::kFail;
@@ -31,10 +33,10 @@ struct HostOps {
 
 struct EmuPlan {
   bc::HostDevPlan h;
-  std::vector<std::vector<uint16_t>> dtables;
+  std::vector<std::vector<uint32_t>> dtables;
 };
 
-template <int NW>
+template <int NW, int NWW>
 void run(const EmuPlan& E, const uint8_t* seq, const uint8_t* qual, const uint16_t* lens, uint32_t stride,
          uint32_t read_len, uint64_t n, uint8_t* outcomes, uint64_t* idx) {
   const uint32_t maxlen = lens ? stride : read_len;
@@ -49,7 +51,8 @@ void run(const EmuPlan& E, const uint8_t* seq, const uint8_t* qual, const uint16
     memcpy((uint8_t*)s32.data() + base, seq + i * stride, stride);
     if (qual) memcpy((uint8_t*)q32.data() + base, qual + i * stride, stride);
     const uint32_t len = lens ? lens[i] : read_len;
-    bc::ReadResult r = bc::process_read<HostOps, NW>(E.h.plan, ops, s32.data(), q32.data(), base, len, nd, true);
+    ops.qual32 = q32.data();
+    bc::ReadResult r = bc::process_read<HostOps, NW, NWW>(E.h.plan, ops, s32.data(), base, len, nd, true);
     outcomes[i] = (uint8_t)r.outcome;
     idx[i] = r.dense_idx;
   }
@@ -79,10 +82,7 @@ void* emu_plan_create(const bc_plan* p) {
     if (G.mode == bc::kSetDirect) {
       const uint32_t nq = 1u << (2 * G.len);
       E->dtables[g].resize(nq);
-      for (uint32_t q = 0; q < nq; ++q) {
-        const uint32_t r = ops.nearest(G, q & bc::lowmask(G.len), q >> G.len, 0, 0, true);
-        E->dtables[g][q] = r == bc::kFail ? bc::kFail16 : (uint16_t)r;
-      }
+      for (uint32_t q = 0; q < nq; ++q) E->dtables[g][q] = bc::dtable_entry(G, q);
       G.dtable = E->dtables[g].data();
     }
   }
@@ -98,14 +98,19 @@ int emu_process(void* e, const uint8_t* seq, const uint8_t* qual, const uint16_t
                 uint32_t read_len, uint64_t n, uint8_t* outcomes, uint64_t* idx) {
   const EmuPlan& E = *(EmuPlan*)e;
   const uint32_t maxlen = lens ? stride : read_len;
-  if (maxlen <= 128)
-    run<4>(E, seq, qual, lens, stride, read_len, n, outcomes, idx);
-  else if (maxlen <= 256)
-    run<8>(E, seq, qual, lens, stride, read_len, n, outcomes, idx);
-  else if (maxlen <= 320)
-    run<10>(E, seq, qual, lens, stride, read_len, n, outcomes, idx);
-  else
+  const uint32_t L = E.h.plan.L;
+  const uint32_t nww = maxlen >= L ? (maxlen - L + 1 + 31) / 32 : 1;
+#define EMU_RUN(NW_, NWW_) run<NW_, NWW_>(E, seq, qual, lens, stride, read_len, n, outcomes, idx)
+  if (maxlen <= 128) {
+    if (nww <= 1) EMU_RUN(4, 1); else if (nww <= 2) EMU_RUN(4, 2); else EMU_RUN(4, 4);
+  } else if (maxlen <= 256) {
+    if (nww <= 2) EMU_RUN(8, 2); else if (nww <= 4) EMU_RUN(8, 4); else EMU_RUN(8, 8);
+  } else if (maxlen <= 320) {
+    if (nww <= 4) EMU_RUN(10, 4); else EMU_RUN(10, 10);
+  } else {
     return -1;
+  }
+#undef EMU_RUN
   return 0;
 }
 }

@@ -61,3 +61,36 @@ def test_plan_matches_oracle_scheme_compile():
         m = pkg.MaxSeqErrors(k["args"][0], k["args"][1], k["args"][2], k["args"][3], k["args"][4], k["args"][5], 0.0,
                              lib=emu_lib.lib())
         assert [m.max_constant_errors(), m.max_sample_errors(), m.max_barcode_errors()] == k["expect"]
+
+
+def _single_n_case(seed, n=1500):
+    """clean constructs whose barcodes carry one or two 'N's, against dense sets with many ties"""
+    rng = np.random.default_rng(seed)
+    c = cases.build_case("del_dense_ties", seed=seed, n=10)
+    samples, counted = list(c["samples"]), c["counted"]
+    reads = []
+    for i in range(n):
+        parts = ["AGCTACGAATCG", "TGGA", "TGGA", "ACTAGAT"]
+        caps = [samples[rng.integers(len(samples))]] + [counted[b][rng.integers(len(counted[b]))] for b in range(3)]
+        caps = [list(readgen.mutate(rng, x, 0.08, 0.0)) for x in caps]
+        for _ in range(1 + (i % 3 == 0)):
+            g = rng.integers(4)
+            caps[g][rng.integers(8)] = "N"
+        caps = ["".join(x) for x in caps]
+        construct = caps[0] + parts[0] + caps[1] + parts[1] + caps[2] + parts[2] + caps[3] + parts[3]
+        off = int(rng.integers(0, 100 - len(construct)))
+        seq = readgen.rand_seq(rng, off) + construct + readgen.rand_seq(rng, 100 - len(construct) - off)
+        reads.append((seq, "I" * 100))
+    c["reads"] = reads
+    c["kwargs"] = dict(max_barcode=int(rng.integers(0, 3)), max_sample=int(rng.integers(0, 3)))
+    return c
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_single_n_captures(seed):
+    c = _single_n_case(seed)
+    plan = emu_lib.make_plan(c)
+    seq, qual, lens = readgen.to_arrays(c["reads"])
+    outc, idx, entries, discard = emu_lib.emulate(plan, seq.reshape(-1), qual.reshape(-1), None, 100, 100)
+    parity.check_per_read(c, plan, outc, idx, discard)
+    assert 0 < int((outc == 0).sum()) < len(outc)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # perf-debug: time the hot kernel with phases switched off (results are wrong when ablated)
-for ab in 0x0 0x1 0x2 0x3 0x4 0x8 0x10 0x20 0x40 0x80 0x7 0x2f 0x6f 0xef; do
+for ab in ${ABL:-0x0 0x1 0x4 0x8 0x24 0x2c 0x2d 0x2f 0x6f 0xef}; do
   BC_ABLATE=$ab python bench.py --reads 20000000 --steps 3 --warmup 1 --no-cpu 2>/dev/null | python -c "
 import json,sys
 try:
