@@ -9,7 +9,7 @@
 namespace bc {
 
 constexpr int kMaxGroups = 18;    // sample + 16 counted barcodes + random
-constexpr int kMaxSteps = 384;    // shift/apply steps per position class
+constexpr int kMaxEntries = 160;  // program entries per position class (up to three positions each)
 constexpr int kMaxRuns = 40;      // quality runs of regions_string
 constexpr int kClasses = 5;       // A, C, T, G constants + scheme-N ([AGCT]) positions
 constexpr int kMaxNW = 10;        // 32-base words per read: reads up to 320 bases
@@ -60,10 +60,18 @@ struct DevPlan {
   uint32_t discard_counts;  // sample file given but no sample group: add_count hits a temporary (info.rs:762-766)
   uint32_t has_fmtn;
   uint32_t ablate;      // perf-debug only (env BC_ABLATE): bit mask of phases to skip; results are then wrong
-  uint32_t n_steps[kClasses];
-  // one byte per step, four steps per dword: shift the vector right by (s & 31); if (s & 0x80)
-  // combine the shifted vector into the accumulator.  One spare dword so a prefetch stays inside.
-  uint32_t steps[kClasses][kMaxSteps / 4 + 1];
+  // Per position class a program that walks the class's format positions in ascending order,
+  // shifting the class vector right by the distance to the next position (0..31 per shift).
+  //   prog_mode 0: prog[0 .. n3) are full triples s1 | s2 << 8 | s3 << 16 (three positions each, a
+  //                branch-free loop), prog[n3] = k << 24 | s1 | s2 << 8 holds the k (0..2) positions left;
+  //   prog_mode 1: (some gap exceeds 31) prog[0 .. n3) are single steps k << 24 | s1, k = 0 meaning
+  //                "shift only".
+  // One spare dword follows every program so that a prefetch stays inside the array.
+  uint32_t n3[kClasses];
+  uint32_t prog_mode[kClasses];
+  uint32_t n_pos[kClasses];  // positions in the class (0: nothing to do)
+  uint32_t prog[kClasses][kMaxEntries + 2];
+  uint32_t cmask[kMaxNW];  // bit p set: format position p is a constant base
   uint32_t run_off[kMaxRuns];   // quality runs in regions_string coordinates
   uint32_t run_len[kMaxRuns];
   uint32_t run_thr[kMaxRuns];   // low <=> sum(scores) < thr   (f32-exact, Appendix A Q10)

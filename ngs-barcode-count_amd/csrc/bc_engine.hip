@@ -22,7 +22,7 @@ namespace bc {
 
 constexpr int kTPB = 256;          // reads (lanes) per workgroup
 #ifndef BC_MIN_WAVES
-#define BC_MIN_WAVES 1  // occupancy floor (waves per SIMD) the register allocator must honour
+#define BC_MIN_WAVES 4  // occupancy floor (waves per SIMD) the register allocator must honour
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -126,7 +126,7 @@ struct DeviceOps {
 // the hot kernel: SequenceParser::parse, 64 reads per wavefront, 4 wavefronts per workgroup
 // ------------------------------------------------------------------------------------------------
 template <int NW, int NWW>
-__global__ __launch_bounds__(kTPB, BC_MIN_WAVES) void match_count_kernel(const DevPlan* __restrict__ plp,
+__global__ __launch_bounds__(kTPB, ((NW <= 4 && NWW <= 2) ? BC_MIN_WAVES : 1)) void match_count_kernel(const DevPlan* __restrict__ plp,
                                                            const uint8_t* __restrict__ seq,
                                                            const uint8_t* __restrict__ qual,
                                                            const uint16_t* __restrict__ lens, uint32_t stride,

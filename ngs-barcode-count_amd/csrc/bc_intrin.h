@@ -26,6 +26,9 @@ BC_HD uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_a
 BC_HD uint32_t sad_u8(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_sad_u8(a, b, c); }
 BC_HD uint32_t popc(uint32_t x) { return __builtin_popcount(x); }
 BC_HD uint32_t ctz(uint32_t x) { return __builtin_ctz(x); }
+// v_bitop3_b32: any boolean function of three operands; bit (a*4 + b*2 + c) of TT is f(a,b,c)
+template <int TT>
+BC_HD uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, TT); }
 #else
 BC_HD uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t s) {
   return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (s & 31));
@@ -56,6 +59,29 @@ BC_HD uint32_t sad_u8(uint32_t a, uint32_t b, uint32_t c) {
 }
 BC_HD uint32_t popc(uint32_t x) { return (uint32_t)__builtin_popcount(x); }
 BC_HD uint32_t ctz(uint32_t x) { return (uint32_t)__builtin_ctz(x); }
+template <int TT>
+BC_HD uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r = 0;
+  for (int i = 0; i < 8; ++i) {
+    if (!((TT >> i) & 1)) continue;
+    r |= ((i & 4) ? a : ~a) & ((i & 2) ? b : ~b) & ((i & 1) ? c : ~c);
+  }
+  return r;
+}
+#endif
+
+// truth tables for bitop3 (operand order a, b, c)
+constexpr int kTT_Xor3 = 0x96, kTT_Xnor3 = 0x69, kTT_Maj = 0xE8, kTT_NotMaj = 0x17;
+constexpr int kTT_AorBandC = 0xF8;  // a | (b & c)
+constexpr int kTT_Xnor2ab = 0xC3;   // ~(a ^ b)      (c ignored)
+constexpr int kTT_Nor2ab = 0x03;    // ~(a | b)      (c ignored)
+
+// Keeps a wave-uniform `if` a real scalar branch: without it the compiler turns the branch into
+// one v_cndmask per candidate value, which costs VALU issue slots in every lane.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BC_KEEP_BRANCH3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
+#else
+#define BC_KEEP_BRANCH3(a, b, c) (void)0
 #endif
 
 // bytes that are zero -> 0x80 in that byte

@@ -151,6 +151,23 @@ BC_HD uint32_t extract_uniform(const uint32_t (&v)[NW], uint32_t off, uint32_t l
   return alignbit(hi, lo, off & 31u) & lowmask(len);
 }
 
+// bits [off, off+len) of the three base planes (off/len wave-uniform, len <= 32): the word is
+// picked by a scalar branch, so each plane costs one funnel shift and one mask
+template <int NW>
+BC_HD void extract_planes(const Planes<NW>& P, uint32_t off, uint32_t len, uint32_t& q1, uint32_t& q2, uint32_t& qn) {
+  const uint32_t k = off >> 5, sh = off & 31u, m = lowmask(len);
+  q1 = q2 = qn = 0;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    if (k == (uint32_t)i) {
+      q1 = alignbit(i + 1 < NW ? P.p1[i + 1] : 0u, P.p1[i], sh) & m;
+      q2 = alignbit(i + 1 < NW ? P.p2[i + 1] : 0u, P.p2[i], sh) & m;
+      qn = alignbit(i + 1 < NW ? P.pn[i + 1] : 0u, P.pn[i], sh) & m;
+      BC_KEEP_BRANCH3(q1, q2, qn);
+    }
+  }
+}
+
 // bit `pos` of a vector, pos per lane
 template <int NW>
 BC_HD uint32_t test_bit(const uint32_t (&v)[NW], uint32_t pos) {
@@ -180,27 +197,254 @@ BC_HD void eq_vector(const Planes<NW>& P, const uint32_t (&inr)[NW], int c, uint
   }
 }
 
-// Runs the shift/apply program of one position class over the vector v (bc_device_plan.h).
-// Steps are packed four to a dword and the next dword is fetched while the current one is being
-// executed, so the scalar loads stay off the critical path.
-template <int NW, class F>
-BC_HD void run_steps(const DevPlan& pl, int c, uint32_t (&v)[NW], F&& apply) {
-  const uint32_t ns = pl.n_steps[c];
-  if (ns == 0) return;
-  const uint32_t* sp = pl.steps[c];
-  uint32_t cur = sp[0];
-  for (uint32_t s0 = 0; s0 < ns; s0 += 4) {
-    const uint32_t nxt = sp[(s0 >> 2) + 1];  // one dword past the program is still inside the array
+template <int NW>
+BC_HD void shr_to(uint32_t (&d)[NW], const uint32_t (&src)[NW], uint32_t sh) {  // sh in [0,31], wave-uniform
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      if (s0 + t < ns) {
-        const uint32_t st = (cur >> (8 * t)) & 0xFFu;
-        shr_uniform<NW>(v, st & 31u);
-        if (st & 0x80u) apply(v);
+  for (int i = 0; i < NW; ++i) d[i] = alignbit(i + 1 < NW ? src[i + 1] : 0u, src[i], sh);
+}
+
+// Bit-sliced counters: cnt[b][w] holds bit b of the mismatch count of every window of word w;
+// counts above 2^NB-1 are remembered in ovf.  add_bits adds, to every window at once, one vector
+// of weight 1 (s) and one of weight 2 (c) -- the sum and carry of a 3:2 compression of three
+// mismatch vectors, so three format positions cost little more than one.
+template <int NWW, int NB>
+struct Counters {
+  uint32_t cnt[NB ? NB : 1][NWW];
+  uint32_t ovf[NWW];
+};
+
+template <int NWW, int NB>
+BC_HD void add_bits(Counters<NWW, NB>& C, int w, uint32_t s, uint32_t c) {
+  if (NB == 0) {
+    C.ovf[w] = bitop3<0xFE>(C.ovf[w], s, c);  // a | b | c
+    return;
+  }
+  const uint32_t t = C.cnt[0][w] & s;
+  C.cnt[0][w] ^= s;
+  if (NB == 1) {
+    C.ovf[w] = bitop3<0xFE>(C.ovf[w], c, t);
+    return;
+  }
+  // weight 2: two incoming bits (c, t)
+  const uint32_t c1 = C.cnt[1][w];
+  C.cnt[1][w] = bitop3<kTT_Xor3>(c1, c, t);
+  uint32_t carry = bitop3<kTT_Maj>(c1, c, t);
+#pragma unroll
+  for (int b = 2; b < NB - 1; ++b) {
+    const uint32_t u = C.cnt[b][w] & carry;
+    C.cnt[b][w] ^= carry;
+    carry = u;
+  }
+  if (NB > 2) {
+    C.ovf[w] = bitop3<kTT_AorBandC>(C.ovf[w], C.cnt[NB - 1][w], carry);
+    C.cnt[NB - 1][w] ^= carry;
+  } else {
+    C.ovf[w] |= carry;
+  }
+}
+
+// Mismatch count of every window against the constant bases of the format (the inner loops of
+// fix_error, parse.rs:562-575, for all windows of fix_constant_region, parse.rs:291-304, at once).
+// A read base equal to the format base, or 'N', is no mismatch (parse.rs:569).
+template <int NW, int NWW, int NB>
+BC_HD void count_mismatches(const DevPlan& pl, const Planes<NW>& P, bool anyx, Counters<NWW, NB>& C) {
+#pragma unroll
+  for (int w = 0; w < NWW; ++w) {
+    C.ovf[w] = 0;
+#pragma unroll
+    for (int b = 0; b < (NB ? NB : 1); ++b) C.cnt[b][w] = 0;
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (pl.n_pos[c] == 0) continue;
+    // v = "base equals letter c, or is 'N'" (N is free, parse.rs:569).  Bits past the read are
+    // not masked: only windows that lie inside the read are ever candidates.
+    uint32_t v[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      // f(p1, p2, pn) = pn | (p1 == c1 & p2 == c2): one instruction per word
+      v[w] = c == 0 ? bitop3<0xAB>(P.p1[w], P.p2[w], P.pn[w])
+           : c == 1 ? bitop3<0xBA>(P.p1[w], P.p2[w], P.pn[w])
+           : c == 2 ? bitop3<0xAE>(P.p1[w], P.p2[w], P.pn[w])
+                    : bitop3<0xEA>(P.p1[w], P.p2[w], P.pn[w]);
+      if (anyx) v[w] &= ~P.px[w];  // a foreign byte never matches
+    }
+    const uint32_t* pp = pl.prog[c];
+    const uint32_t n = pl.n3[c];
+    uint32_t cur = pp[0];
+    if (pl.prog_mode[c] == 0u) {
+      // three positions per iteration, no branch inside: x, y, z are the match vectors at the
+      // three positions, their complements the mismatch bits
+      for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t nxt = pp[i + 1];
+        uint32_t a[NW], b[NW];
+        shr_to<NW>(a, v, cur & 31u);
+        shr_to<NW>(b, a, (cur >> 8) & 31u);
+        shr_to<NW>(v, b, (cur >> 16) & 31u);
+#pragma unroll
+        for (int w = 0; w < NWW; ++w) {
+          add_bits<NWW, NB>(C, w, bitop3<kTT_Xnor3>(a[w], b[w], v[w]), bitop3<kTT_NotMaj>(a[w], b[w], v[w]));
+        }
+        cur = nxt;
+      }
+      const uint32_t k = cur >> 24;  // the positions left over: 0, 1 or 2
+      if (k == 2u) {
+        uint32_t a[NW], b[NW];
+        shr_to<NW>(a, v, cur & 31u);
+        shr_to<NW>(b, a, (cur >> 8) & 31u);
+#pragma unroll
+        for (int w = 0; w < NWW; ++w) add_bits<NWW, NB>(C, w, a[w] ^ b[w], bitop3<kTT_Nor2ab>(a[w], b[w], 0u));
+      } else if (k == 1u) {
+        uint32_t a[NW];
+        shr_to<NW>(a, v, cur & 31u);
+#pragma unroll
+        for (int w = 0; w < NWW; ++w) add_bits<NWW, NB>(C, w, ~a[w], 0u);
+      }
+    } else {
+      for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t e = pp[i];
+        shr_uniform<NW>(v, e & 31u);
+        if (e >> 24) {
+#pragma unroll
+          for (int w = 0; w < NWW; ++w) add_bits<NWW, NB>(C, w, ~v[w], 0u);
+        }
       }
     }
-    cur = nxt;
   }
+}
+
+// AND of the class vector over the class's positions, for every window (scheme-N positions)
+template <int NW, int NWW>
+BC_HD void and_program(const DevPlan& pl, int c, uint32_t (&v)[NW], uint32_t (&acc)[NWW]) {
+  const uint32_t* pp = pl.prog[c];
+  const uint32_t n = pl.n3[c];
+  const bool singles = pl.prog_mode[c] != 0u;
+  for (uint32_t i = 0; i <= n; ++i) {
+    if (singles && i == n) break;
+    const uint32_t e = pp[i];
+    // triples mode: three positions per entry, then the k left over; singles mode: k in the entry
+    const uint32_t steps = singles ? 1u : (i < n ? 3u : (e >> 24));
+    const bool use = singles ? (e >> 24) != 0u : true;
+    for (uint32_t t = 0; t < steps; ++t) {
+      shr_uniform<NW>(v, (e >> (8 * t)) & 31u);
+      if (use) {
+#pragma unroll
+        for (int w = 0; w < NWW; ++w) acc[w] &= v[w];
+      }
+    }
+  }
+}
+
+// Anchor + repair for one read.  Returns true when a construct was located: `start` is its
+// offset and `repaired` says whether the constant region had to be repaired.
+//  * exact anchor (Regex::is_match / captures, parse.rs:92-95, 153-156): the leftmost window with
+//    no mismatch, no 'N' on a constant position, and valid bases on the scheme-N positions;
+//  * otherwise fix_constant_region (parse.rs:287-313): among the windows 0 .. len-L-1 (the last
+//    window is never tested, parse.rs:291-295) the unique minimum-mismatch window within the
+//    budget (fix_error, parse.rs:577-592), provided its scheme-N positions are valid bases.
+template <class Ops, int NW, int NWW, int NB>
+BC_HD bool locate(const DevPlan& pl, Ops& ops, const Planes<NW>& P, const uint32_t (&inr)[NW], uint32_t len, bool live,
+                  bool anyx, uint32_t& start, bool& repaired) {
+  const uint32_t L = pl.L;
+  Counters<NWW, NB> C;
+  count_mismatches<NW, NWW, NB>(pl, P, anyx, C);
+
+  uint32_t fnok[NWW];
+#pragma unroll
+  for (int w = 0; w < NWW; ++w) fnok[w] = 0xFFFFFFFFu;
+  if (pl.has_fmtn) {  // [AGCT]{n}, info.rs:291-294
+    uint32_t v[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v[w] = inr[w] & ~(P.pn[w] | P.px[w]);
+    and_program<NW, NWW>(pl, kClassFmtN, v, fnok);
+  }
+
+  // windows without any mismatch ('N' still free)
+  uint32_t z[NWW];
+  low_bits<NWW>(z, len >= L ? len - L + 1u : 0u);
+  uint32_t anyn = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) anyn |= P.pn[w];
+#pragma unroll
+  for (int w = 0; w < NWW; ++w) {
+    z[w] &= ~C.ovf[w] & fnok[w];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) z[w] &= ~C.cnt[b][w];
+  }
+  bool found = false;
+  start = 0;
+  repaired = false;
+  for (;;) {
+    uint32_t o = 0, any = 0;
+#pragma unroll
+    for (int w = NWW - 1; w >= 0; --w) {
+      if (z[w]) {
+        o = 32u * (uint32_t)w + ctz(z[w]);
+        any = 1;
+      }
+    }
+    if (!any) break;
+    bool nfree = true;
+    if (anyn) {  // the regex needs the literal base: an 'N' on a constant position is no match
+      uint32_t t[NW];
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t[w] = P.pn[w];
+      shr_lane<NW>(t, o);
+      uint32_t hit = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) hit |= t[w] & pl.cmask[w];
+      nfree = hit == 0u;
+    }
+    if (nfree) {
+      found = true;
+      start = o;
+      break;
+    }
+#pragma unroll
+    for (int w = 0; w < NWW; ++w)
+      if ((o >> 5) == (uint32_t)w) z[w] &= ~(1u << (o & 31u));
+  }
+
+  if (!(pl.ablate & 0x1u) && ops.any(live && !found)) {
+    uint32_t cand[NWW];
+    low_bits<NWW>(cand, len > L ? len - L : 0u);
+#pragma unroll
+    for (int w = 0; w < NWW; ++w) cand[w] &= ~C.ovf[w];
+#pragma unroll
+    for (int b = NB - 1; b >= 0; --b) {
+      uint32_t t[NWW];
+      uint32_t nz = 0;
+#pragma unroll
+      for (int w = 0; w < NWW; ++w) {
+        t[w] = cand[w] & ~C.cnt[b][w];
+        nz |= t[w];
+      }
+#pragma unroll
+      for (int w = 0; w < NWW; ++w) cand[w] = nz ? t[w] : cand[w];
+    }
+    uint32_t n_min = 0, val = 0, pos = 0;
+#pragma unroll
+    for (int w = NWW - 1; w >= 0; --w) {
+      n_min += popc(cand[w]);
+      if (cand[w]) pos = 32u * (uint32_t)w + ctz(cand[w]);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      uint32_t o = 0;
+#pragma unroll
+      for (int w = 0; w < NWW; ++w) o |= cand[w] & C.cnt[b][w];
+      val |= (o ? 1u : 0u) << b;
+    }
+    // the window replaces the read, constants overwritten by the format
+    // (insert_barcodes_constant_region, parse.rs:270-283); the regex then has to match it at
+    // offset 0, which only the scheme-N positions can still prevent
+    if (!found && n_min == 1u && val <= pl.max_const && test_bit<NWW>(fnok, pos)) {
+      found = true;
+      repaired = true;
+      start = pos;
+    }
+  }
+  return found;
 }
 
 // ---- quality (RawSequenceRead::low_quality, parse.rs:331-375) ----------------------------------
@@ -305,79 +549,6 @@ BC_HD uint32_t single_n_lookup(const DevGroup& G, uint32_t q1, uint32_t q2, uint
   return (ok && best <= G.max_err && res != (uint32_t)kFail16) ? res : kFail;
 }
 
-// Constant-region repair for every window of one read at once (fix_constant_region,
-// parse.rs:287-313): the mismatch count of window i is accumulated in NB bit-sliced counter bits
-// (counts above 2^NB-1 go to an overflow mask), then the unique minimum is searched bit by bit.
-// Returns true and the window index when exactly one window has the smallest count and that
-// count is within the budget (fix_error, parse.rs:577-592).
-template <int NW, int NWW, int NB>
-BC_HD bool repair_search(const DevPlan& pl, const Planes<NW>& P, const uint32_t (&inr)[NW], uint32_t len, uint32_t& pos) {
-  const uint32_t L = pl.L;
-  // windows 0 .. len-L-1 only: the last window is never tested (parse.rs:291-295)
-  uint32_t cand[NWW];
-  low_bits<NWW>(cand, len > L ? len - L : 0u);
-  uint32_t cnt[NB][NWW];
-  uint32_t ovf[NWW];
-#pragma unroll
-  for (int w = 0; w < NWW; ++w) {
-    ovf[w] = 0;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) cnt[b][w] = 0;
-  }
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    if (pl.n_steps[c]) {
-      uint32_t v[NW];
-      eq_vector<NW>(P, inr, c, v);
-      // mismatch = differs and neither side is 'N' (parse.rs:569); format 'N's are not in the program
-#pragma unroll
-      for (int w = 0; w < NW; ++w) v[w] = inr[w] & ~P.pn[w] & ~v[w];
-      run_steps<NW>(pl, c, v, [&](const uint32_t (&x)[NW]) {
-#pragma unroll
-        for (int w = 0; w < NWW; ++w) {
-          uint32_t carry = x[w];
-#pragma unroll
-          for (int b = 0; b < NB; ++b) {
-            const uint32_t t = cnt[b][w] & carry;
-            cnt[b][w] ^= carry;
-            carry = t;
-          }
-          ovf[w] |= carry;
-        }
-      });
-    }
-  }
-#pragma unroll
-  for (int w = 0; w < NWW; ++w) cand[w] &= ~ovf[w];
-#pragma unroll
-  for (int b = NB - 1; b >= 0; --b) {
-    uint32_t t[NWW];
-    uint32_t nz = 0;
-#pragma unroll
-    for (int w = 0; w < NWW; ++w) {
-      t[w] = cand[w] & ~cnt[b][w];
-      nz |= t[w];
-    }
-#pragma unroll
-    for (int w = 0; w < NWW; ++w) cand[w] = nz ? t[w] : cand[w];
-  }
-  uint32_t n_min = 0, val = 0;
-  pos = 0;
-#pragma unroll
-  for (int w = NWW - 1; w >= 0; --w) {
-    n_min += popc(cand[w]);
-    if (cand[w]) pos = 32u * (uint32_t)w + ctz(cand[w]);
-  }
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    uint32_t o = 0;
-#pragma unroll
-    for (int w = 0; w < NWW; ++w) o |= cand[w] & cnt[b][w];
-    val |= (o ? 1u : 0u) << b;
-  }
-  return n_min == 1u && val <= pl.max_const;
-}
-
 // ---- the per-read decision tree ---------------------------------------------------------------
 struct ReadResult {
   uint32_t outcome;    // Outcome; kMatched means "passed every test" (duplicate detection is later)
@@ -425,70 +596,23 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
     P.px[w] &= inr[w];
   }
 
-  const uint32_t L = pl.L;
-  // ---- leftmost exact anchor: Regex::is_match / captures (parse.rs:92-95, 153-156) -------------
-  uint32_t acc[NWW];
-  low_bits<NWW>(acc, len >= L ? len - L + 1u : 0u);  // offsets o with o + L <= len
-  if (!(pl.ablate & 0x10u)) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      if (pl.n_steps[c]) {
-        uint32_t v[NW];
-        eq_vector<NW>(P, inr, c, v);
-        run_steps<NW>(pl, c, v, [&](const uint32_t (&x)[NW]) {
-#pragma unroll
-          for (int w = 0; w < NWW; ++w) acc[w] &= x[w];
-        });
-      }
-    }
-  }
-  // scheme 'N' positions must be one of A,G,C,T ([AGCT]{n}, info.rs:291-294)
-  uint32_t fnok[NWW];
-#pragma unroll
-  for (int w = 0; w < NWW; ++w) fnok[w] = 0xFFFFFFFFu;
-  if (pl.has_fmtn) {
-    uint32_t v[NW];
-#pragma unroll
-    for (int w = 0; w < NW; ++w) v[w] = inr[w] & ~(P.pn[w] | P.px[w]);
-    run_steps<NW>(pl, kClassFmtN, v, [&](const uint32_t (&x)[NW]) {
-#pragma unroll
-      for (int w = 0; w < NWW; ++w) fnok[w] &= x[w];
-    });
-#pragma unroll
-    for (int w = 0; w < NWW; ++w) acc[w] &= fnok[w];
-  }
+  // ---- locate the construct: exact anchor, else constant-region repair -----------------------------
   uint32_t start = 0;
-  bool found = false;
-#pragma unroll
-  for (int w = NWW - 1; w >= 0; --w) {
-    if (acc[w]) {
-      start = 32u * (uint32_t)w + ctz(acc[w]);
+  bool repaired = false, found = false;
+  {
+    const bool live = active && !unsupported;
+    // counter width is a compile-time constant; any width whose range covers max_const (or none
+    // at all when no mismatch is allowed) gives the same verdicts
+    if (pl.ablate & 0x10u) {
       found = true;
-    }
-  }
-
-  // ---- constant-region repair: fix_constant_region (parse.rs:287-313) --------------------------
-  bool repaired = false;
-  if (!(pl.ablate & 0x1u) && ops.any(active && !found && !unsupported)) {
-    // counter width is a compile-time constant (a runtime width costs three selects per bit):
-    // any width whose range covers max_const gives the same verdicts
-    uint32_t pos = 0;
-    bool ok;
-    if (pl.nb <= 2u)
-      ok = repair_search<NW, NWW, 2>(pl, P, inr, len, pos);
-    else if (pl.nb == 3u)
-      ok = repair_search<NW, NWW, 3>(pl, P, inr, len, pos);
-    else
-      ok = repair_search<NW, NWW, 5>(pl, P, inr, len, pos);
-    if (!found && ok) {
-      // the window replaces the read, constants overwritten by the format
-      // (insert_barcodes_constant_region, parse.rs:270-283); the regex then has to match it
-      // at offset 0, which only the scheme-N positions can still prevent
-      if (test_bit<NWW>(fnok, pos)) {
-        found = true;
-        repaired = true;
-        start = pos;
-      }
+    } else if (pl.max_const == 0u) {
+      found = locate<Ops, NW, NWW, 0>(pl, ops, P, inr, len, live, anyx, start, repaired);
+    } else if (pl.nb <= 2u) {
+      found = locate<Ops, NW, NWW, 2>(pl, ops, P, inr, len, live, anyx, start, repaired);
+    } else if (pl.nb == 3u) {
+      found = locate<Ops, NW, NWW, 3>(pl, ops, P, inr, len, live, anyx, start, repaired);
+    } else {
+      found = locate<Ops, NW, NWW, 5>(pl, ops, P, inr, len, live, anyx, start, repaired);
     }
   }
 
@@ -536,9 +660,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
       if (g0 + u < ng) {  // wave-uniform
         const DevGroup& G = pl.groups[g0 + u];
         if (G.mode != kSetNone) {
-          q1[u] = extract_uniform<NW>(P.p1, G.off, G.len);
-          q2[u] = extract_uniform<NW>(P.p2, G.off, G.len);
-          qn[u] = extract_uniform<NW>(P.pn, G.off, G.len);
+          extract_planes<NW>(P, G.off, G.len, q1[u], q2[u], qn[u]);
           if (anyx) qx[u] = extract_uniform<NW>(P.px, G.off, G.len);
           const bool clean = (qn[u] | qx[u]) == 0u;
           if (pre_ok) {

@@ -182,26 +182,48 @@ bool bc_plan::lower(HostDevPlan& out) const {
       where[kClassFmtN].push_back(p);
   }
   for (int c = 0; c < kClasses; ++c) {
-    uint32_t cur = 0, n = 0;
+    std::vector<uint32_t> deltas;
+    uint32_t cur = 0;
+    bool gap = false;
     for (uint32_t p : where[c]) {
-      uint32_t delta = p - cur;
-      auto put = [&](uint32_t st) {
-        P.steps[c][n >> 2] |= st << (8 * (n & 3));
-        ++n;
-      };
-      while (delta > 31 && n < (uint32_t)kMaxSteps) {
-        put(31);
-        delta -= 31;
-      }
-      if (n >= (uint32_t)kMaxSteps) {
+      deltas.push_back(p - cur);
+      gap = gap || (p - cur) > 31;
+      cur = p;
+    }
+    P.n_pos[c] = (uint32_t)deltas.size();
+    uint32_t n = 0;
+    if (!gap) {
+      P.prog_mode[c] = 0;
+      size_t i = 0;
+      for (; i + 3 <= deltas.size() && n < (uint32_t)kMaxEntries; i += 3)
+        P.prog[c][n++] = deltas[i] | (deltas[i + 1] << 8) | (deltas[i + 2] << 16);
+      if (i + 3 <= deltas.size()) {
         set_error("unsupported scheme: too many constant positions");
         return false;
       }
-      put(delta | 0x80u);
-      cur = p;
+      const uint32_t k = (uint32_t)(deltas.size() - i);
+      uint32_t e = k << 24;
+      for (uint32_t t = 0; t < k; ++t) e |= deltas[i + t] << (8 * t);
+      P.n3[c] = n;
+      P.prog[c][n] = e;
+    } else {
+      P.prog_mode[c] = 1;
+      for (uint32_t d : deltas) {
+        while (d > 31 && n < (uint32_t)kMaxEntries) {
+          P.prog[c][n++] = 31u;  // k = 0: shift only
+          d -= 31;
+        }
+        if (n >= (uint32_t)kMaxEntries) {
+          set_error("unsupported scheme: too many constant positions");
+          return false;
+        }
+        P.prog[c][n++] = (1u << 24) | d;
+      }
+      P.n3[c] = n;
     }
-    P.n_steps[c] = n;
   }
+  for (uint32_t p = 0; p < pos.size(); ++p)
+    if (pos[p].kind == kPosConst) P.cmask[p >> 5] |= 1u << (p & 31);
   P.has_fmtn = where[kClassFmtN].empty() ? 0u : 1u;
 
   // quality runs: maximal stretches of one non-'C' letter of regions_string (parse.rs:340-372)

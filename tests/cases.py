@@ -9,6 +9,7 @@ EXAMPLE_SCHEME = "[10]\nAGCTACGAATCG\n{6}\nTGGA\n{6}\nTGGA\n{6}\nACTAGAT\n(8)\nT
 CRISPR_SCHEME = "TTGTGGAAAGGACGAAACACCG{20}GTTTTAGAGCTAGAAATAGCAAGTT"
 FMTN_SCHEME = "[6]ACGTNNACGT{7}TTGNCA{5}GGATCC"
 NOSAMPLE_SCHEME = "GATTACA{9}CCTAGG{4}TTAACCGG"
+GAP_SCHEME = "[32]AC{32}GT{8}ACGGT"  # first constant at position 32 and 34-base gaps: shift-only steps
 
 
 def build_case(name, seed=0, n=600):
@@ -99,6 +100,13 @@ def build_case(name, seed=0, n=600):
         c["counted"] = [readgen.make_set(rng, 40, 8, 2) for _ in range(3)]
         c["reads"] = readgen.gen_reads(rng, DEL_SCHEME, n, 100, s, c["counted"], p_sub=0.01, p_n=0.002,
                                        p_other=0.01)
+    elif name == "long_gaps":
+        c["scheme"] = GAP_SCHEME
+        s = readgen.make_set(rng, 3, 32, 6)
+        c["samples"] = {x: "S%d" % i for i, x in enumerate(s)}
+        c["counted"] = [readgen.make_set(rng, 12, 32, 6), readgen.make_set(rng, 30, 8, 2)]
+        c["kwargs"] = dict(min_quality=21.0, max_constant=2)
+        c["reads"] = readgen.gen_reads(rng, GAP_SCHEME, n, 120, s, c["counted"], p_sub=0.01, p_n=0.002)
     else:
         raise KeyError(name)
     return c
@@ -106,4 +114,4 @@ def build_case(name, seed=0, n=600):
 
 ALL_CASES = ["del_exact", "del_mismatch_quality", "del_dense_ties", "del_random", "example_files",
              "example_files_samples", "crispr", "fmtn", "nosample_with_sample_file", "nosample",
-             "refs_with_n_and_ragged", "other_chars"]
+             "refs_with_n_and_ragged", "other_chars", "long_gaps"]
