@@ -30,6 +30,7 @@ import torch
 import torch.distributed as dist
 
 import ngs_barcode_count_amd as pkg
+from ngs_barcode_count_amd import distributed as bcdist
 import workloads
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
@@ -93,7 +94,8 @@ def main():
     # --- resident inputs: this rank's contiguous shard of the seeded read stream -------------------
     dseq = torch.empty(n * R, dtype=torch.uint8, device=dev)
     dqual = torch.empty(n * R, dtype=torch.uint8, device=dev)
-    w.synth.generate_device(local, None, rank * n, n, dseq.data_ptr(), dqual.data_ptr())
+    first_read, _ = bcdist.shard(n * world, rank, world)
+    w.synth.generate_device(local, None, first_read, n, dseq.data_ptr(), dqual.data_ptr())
     torch.cuda.synchronize()
     table = torch.zeros(w.plan.table_entries, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
@@ -123,7 +125,7 @@ def main():
     reduce_ms = 0.0
     if world > 1:
         tr = time.perf_counter()
-        dist.reduce(table, dst=0, op=dist.ReduceOp.SUM)  # the job's single RCCL reduce of the counter tables
+        bcdist.reduce_table(table, dst=0)  # the job's single RCCL reduce of the counter tables
         torch.cuda.synchronize()
         reduce_ms = (time.perf_counter() - tr) * 1e3
     barrier()
@@ -134,7 +136,7 @@ def main():
         elapsed, t_steps, reduce_ms = t.tolist()
 
     kernel_ms, launches = eng.kernel_ms()
-    counters = eng.counters()
+    counters = bcdist.reduce_counters(eng.counters(), dev, dst=0)
     total_reads = n * args.steps * world
     if rank != 0:
         if world > 1:
@@ -142,11 +144,27 @@ def main():
         return
 
     six = sum(counters[k] for k in ("matched", "constant_region", "sample_barcode", "barcode", "duplicates", "low_quality"))
-    assert os.environ.get("BC_ABLATE") or six == n * args.steps == counters["total_reads"], counters
+    assert os.environ.get("BC_ABLATE") or six == total_reads == counters["total_reads"], counters
     f_matched = counters["matched"] / max(counters["total_reads"], 1)
     b_alg = workloads.bytes_per_read(w, f_matched)
     avg_ms = kernel_ms / max(launches, 1)
     achieved = (b_alg * n) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+
+    # HBM bytes per launch from the PMC counters (FETCH_SIZE doubled per the gfx950 correction,
+    # + WRITE_SIZE), measured by tools_profile.sh in separate rocprofv3 passes of this very workload
+    # and committed under profiles/; null when no summary of this workload size exists
+    traffic, traffic_src = None, None
+    try:
+        prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json"))
+        for f in reversed(prof):
+            js = json.load(open(os.path.join(ROOT, "profiles", f)))
+            wl = js.get("_workload", "")
+            if args.config in wl and "{:,}".format(n) in wl and "hbm_traffic_bytes_per_dispatch" in js:
+                traffic = js["hbm_traffic_bytes_per_dispatch"]["total"]
+                traffic_src = "profiles/" + f
+                break
+    except OSError:
+        pass
 
     out = {
         "metric": "reads/sec (whole node), 3x8nt DEL vs 3x1k refs" if args.config != "config5" else "reads/sec (whole node), CRISPR 20nt vs 100k guides",
@@ -164,7 +182,8 @@ def main():
         "config": {"workload": WORKLOAD_TEXT[args.config], "config": args.config, "reads_per_step_per_gpu": n,
                    "read_len": R, "parallelism": "reads sharded over %d GPU(s); 1 RCCL sum-reduce of the counter table" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "match_count_kernel<4>",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "alg_bytes_per_launch": b_alg * n, "kernel": "match_count_kernel<4,2>",
                      "kernel_avg_ms": avg_ms, "launches": launches, "alg_bytes_per_read": b_alg,
                      "kernel_reads_per_s": n / (avg_ms * 1e-3) if avg_ms > 0 else 0.0,
                      "frac_of_measured_copy_ceiling_6290": achieved / 6290.0},

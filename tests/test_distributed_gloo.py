@@ -1,0 +1,84 @@
+"""N > 1 path on CPU: two gloo ranks shard a seeded read stream, build their dense counter tables
+(with the test-only host emulation of the kernel -- there is no GPU here), and combine them with
+the product's reduce helpers; rank 0 must hold exactly what one process computes over all reads."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_TOTAL = 3001  # odd on purpose: ranks get unequal shards
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_path):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import emu_lib
+    import parity
+    import workloads
+    from ngs_barcode_count_amd import distributed as bcdist
+
+    w = workloads.make("config3", n_sets=(4, 40, 40, 40), lib=None)
+    first, count = bcdist.shard(N_TOTAL, rank, world)
+    seq, qual = w.synth.generate_host(first, count)
+    # this rank's table and counters (host emulation of the kernel's lane code; TEST ONLY)
+    import ngs_barcode_count_amd as pkg
+    eplan = pkg.Plan(w.scheme, lib=emu_lib.lib())
+    for i, s in enumerate(w.samples):
+        eplan.add_sample(s, "sample_%d" % i)
+    for b, refs in enumerate(w.counted):
+        for i, s in enumerate(refs):
+            eplan.add_counted(b, s, "bb%d_%d" % (b + 1, i))
+    eplan.set_min_quality(20.0)
+    outc, idx, entries, discard = emu_lib.emulate(eplan, seq, qual, None, 100, 100)
+    table = torch.from_numpy(np.bincount(idx[outc == 0].astype(np.int64), minlength=entries).astype(np.int32))
+    counters = {k: int((outc == i).sum()) for i, k in enumerate(pkg.COUNTER_NAMES)}
+    counters["total_reads"] = count
+    counters["unsupported_reads"] = 0
+    # the product's N > 1 logic
+    bcdist.reduce_table(table, dst=0)
+    total = bcdist.reduce_counters(counters, torch.device("cpu"), dst=0)
+    if rank == 0:
+        nz = torch.nonzero(table).flatten().numpy()
+        rows = parity.decode_rows(eplan, {int(i): int(table[i]) for i in nz}, False)
+        allseq, allqual = w.synth.generate_host(0, N_TOTAL)
+        o = workloads.oracle_for(w)
+        o.process_batch(allseq, allqual, 100, 100)
+        ok = rows == o.rows() and all(total[k] == v for k, v in o.counters.items()) and total["total_reads"] == N_TOTAL
+        with open(out_path, "w") as f:
+            f.write("ok" if ok else "MISMATCH %r vs %r" % (total, o.counters))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_shard_and_reduce(tmp_path):
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert open(out).read() == "ok"
+
+
+def test_shards_tile_the_read_range():
+    from ngs_barcode_count_amd import distributed as bcdist
+    for n in (0, 1, 7, 100, 3001):
+        for world in (1, 2, 3, 8):
+            spans = [bcdist.shard(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+            for (f0, c0), (f1, _) in zip(spans, spans[1:]):
+                assert f0 + c0 == f1
