@@ -34,11 +34,13 @@ from ngs_barcode_count_amd import distributed as bcdist
 import workloads
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
-DEFAULT_READS = {"config2": 10_000_000, "config3": 100_000_000, "config5": 20_000_000}
+DEFAULT_READS = {"config2": 10_000_000, "config3": 100_000_000, "config4": 50_000_000, "config5": 20_000_000}
 WORKLOAD_TEXT = {
     "config2": "DEL [8]+3x{8} vs 4 samples + 3x1000 refs, clean reads, exact match only (BASELINE configs[1])",
     "config3": "DEL [8]+3x{8} vs 4 samples + 3x1000 refs, 1% substitutions + 0.1% N, 20% mismatch budgets, "
                "--min-quality 20 (BASELINE configs[2])",
+    "config4": "DEL [8]+3x{8}+(12) random barcode vs 4 samples + 3x1000 refs, PCR duplicates (2 reads per molecule), "
+               "1% substitutions + 0.1% N (BASELINE configs[3], per-GPU shard of 50M reads; set cleared every step)",
     "config5": "CRISPR {20} vs 100k guides, 1% substitutions + 0.1% N, <=4 mismatches (BASELINE configs[4], per-GPU shard)",
 }
 
@@ -86,8 +88,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    w = workloads.make(args.config)
     n = args.reads or DEFAULT_READS[args.config]
+    w = workloads.make(args.config, n_molecules=(n * world) // 2 if args.config == "config4" else None)
     R = w.read_len
     with_qual = w.min_quality > 0
 
@@ -102,7 +104,11 @@ def main():
     eng = pkg.Engine(w.plan, device=local, table_ptr=table.data_ptr())
     qptr = dqual.data_ptr() if with_qual else None
 
+    random_mode = w.plan.random_barcode
+
     def step():
+        if random_mode:
+            eng.clear_keys()  # a step is one whole job: otherwise every later step would see only duplicates
         eng.submit_device(dseq.data_ptr(), qptr, n, R, R)
 
     def barrier():
@@ -123,9 +129,15 @@ def main():
     eng.sync()
     t_steps = time.perf_counter() - t0
     reduce_ms = 0.0
+    fixed_counters = None
     if world > 1:
         tr = time.perf_counter()
-        bcdist.reduce_table(table, dst=0)  # the job's single RCCL reduce of the counter tables
+        if random_mode:
+            # set sizes do not add: exchange the keys so that each has one owner, then
+            # the per-tuple distinct counts may be summed (done by the root at output time)
+            fixed_counters = bcdist.finish_random(eng, dev, dst=0)
+        else:
+            bcdist.reduce_table(table, dst=0)  # the job's single RCCL reduce of the counter tables
         torch.cuda.synchronize()
         reduce_ms = (time.perf_counter() - tr) * 1e3
     barrier()
@@ -136,7 +148,7 @@ def main():
         elapsed, t_steps, reduce_ms = t.tolist()
 
     kernel_ms, launches = eng.kernel_ms()
-    counters = bcdist.reduce_counters(eng.counters(), dev, dst=0)
+    counters = fixed_counters if fixed_counters is not None else bcdist.reduce_counters(eng.counters(), dev, dst=0)
     total_reads = n * args.steps * world
     if rank != 0:
         if world > 1:
@@ -144,7 +156,7 @@ def main():
         return
 
     six = sum(counters[k] for k in ("matched", "constant_region", "sample_barcode", "barcode", "duplicates", "low_quality"))
-    assert os.environ.get("BC_ABLATE") or six == total_reads == counters["total_reads"], counters
+    assert os.environ.get("BC_ABLATE") or random_mode or six == total_reads == counters["total_reads"], counters
     f_matched = counters["matched"] / max(counters["total_reads"], 1)
     b_alg = workloads.bytes_per_read(w, f_matched)
     avg_ms = kernel_ms / max(launches, 1)

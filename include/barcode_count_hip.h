@@ -142,6 +142,18 @@ int bc_engine_finish(bc_engine *e, uint64_t *n_rows);
 int bc_engine_rows(bc_engine *e, uint64_t first, uint64_t n, uint32_t *sample_idx, uint32_t *barcode_idx,
                    uint64_t *count);
 
+/* Random-barcode schemes (PCR-duplicate collapse, Results::add_count info.rs:770-802): the engine
+ * keeps the set of distinct (sample, barcode tuple, random barcode) keys in a device hash set; a
+ * read whose key is already present counts as BC_DUPLICATES (parse.rs:65-69) and the count of a
+ * tuple is the number of its distinct random barcodes (output.rs:265-270; bc_engine_finish turns
+ * the set into the dense table).  A key is tuple_index * 5^len + base-5 code of the random barcode
+ * (A,C,T,G,N = 0..4).  Across GPUs a sum of tables would be wrong: export the
+ * keys, exchange them so that every key has one owner, import, then reduce.  Device pointers. */
+int bc_engine_key_count(bc_engine *e, uint64_t *n);
+int bc_engine_export_keys(bc_engine *e, void *d_keys, uint64_t capacity, uint64_t *n);
+int bc_engine_import_keys(bc_engine *e, const void *d_keys, uint64_t n, uint64_t *n_new);
+int bc_engine_clear_keys(bc_engine *e);
+
 /* Debug / parity-test hook: the next submits also write, for read i of the submit, its outcome
  * (BC_* counter index; BC_MATCHED = passed every test) to d_outcome_u8[i] and its dense table index
  * to d_index_u64[i].  Both device pointers; NULL switches tracing off. */

@@ -169,6 +169,25 @@ class Engine:
         """per-read outcome / dense index written by the next submits (tests); None disables"""
         _check(self._lib, self._lib.bc_engine_trace(self._e, d_outcome_u8, d_index_u64))
 
+    # random-barcode mode: the set of (tuple, random barcode) keys
+    def key_count(self):
+        n = C.c_uint64()
+        _check(self._lib, self._lib.bc_engine_key_count(self._e, C.byref(n)))
+        return n.value
+
+    def export_keys(self, d_keys, capacity):
+        n = C.c_uint64()
+        _check(self._lib, self._lib.bc_engine_export_keys(self._e, d_keys, capacity, C.byref(n)))
+        return n.value
+
+    def import_keys(self, d_keys, n):
+        new = C.c_uint64()
+        _check(self._lib, self._lib.bc_engine_import_keys(self._e, d_keys, n, C.byref(new)))
+        return new.value
+
+    def clear_keys(self):
+        _check(self._lib, self._lib.bc_engine_clear_keys(self._e))
+
     def timing(self, enable=True):
         _check(self._lib, self._lib.bc_engine_timing(self._e, 1 if enable else 0))
 

@@ -72,6 +72,10 @@ ENGINE_API = {
     "bc_engine_timing": (_int, [_vp, _int]),
     "bc_engine_kernel_ms": (_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "bc_engine_trace": (_int, [_vp, _vp, _vp]),
+    "bc_engine_key_count": (_int, [_vp, C.POINTER(C.c_uint64)]),
+    "bc_engine_export_keys": (_int, [_vp, _vp, _u64, C.POINTER(C.c_uint64)]),
+    "bc_engine_import_keys": (_int, [_vp, _vp, _u64, C.POINTER(C.c_uint64)]),
+    "bc_engine_clear_keys": (_int, [_vp]),
     "bc_fix_error": (C.c_int64, [_cp, C.POINTER(_cp), _u64, C.c_uint16, _int]),
     "bc_synth_create": (_vp, [_vp, C.POINTER(SynthParams)]),
     "bc_synth_destroy": (None, [_vp]),

@@ -59,6 +59,10 @@ struct DevPlan {
   uint32_t n_runs;
   uint32_t discard_counts;  // sample file given but no sample group: add_count hits a temporary (info.rs:762-766)
   uint32_t has_fmtn;
+  // random barcode (PCR-duplicate collapse, info.rs:770-802): the capture is kept raw; its base-5
+  // code (A,C,T,G,N -> 0,1,2,3,4) and the dense tuple index form one 64-bit key of a device hash set
+  uint32_t has_random, rnd_off, rnd_len, rnd_pad;
+  uint64_t rspace;      // 5^rnd_len: key = dense_idx * rspace + code
   uint32_t ablate;      // perf-debug only (env BC_ABLATE): bit mask of phases to skip; results are then wrong
   // Per position class a program that walks the class's format positions in ascending order,
   // shifting the class vector right by the distance to the next position (0..31 per shift).

@@ -90,6 +90,20 @@ __device__ __forceinline__ void stage_tile(uint8_t* __restrict__ dst, const uint
   for (uint32_t i = bytes + lane; i < region; i += 64) dst[i] = pad;
 }
 
+// ---- device hash set of 64-bit keys (the AHashSet<String> per tuple of info.rs:663, flattened) ----
+constexpr unsigned long long kEmptyKey = ~0ull;
+
+// true when the key was not in the set before
+__device__ __forceinline__ bool set_insert(unsigned long long* __restrict__ slots, uint64_t mask, uint64_t key) {
+  uint64_t h = hash64(key) & mask;
+  for (;;) {
+    const unsigned long long old = atomicCAS(&slots[h], kEmptyKey, (unsigned long long)key);
+    if (old == kEmptyKey) return true;
+    if (old == key) return false;
+    h = (h + 1) & mask;
+  }
+}
+
 struct DeviceOps {
   uint8_t* tile;          // this wave's LDS region
   const uint8_t* qsrc;    // this wave's quality lines in global memory
@@ -132,6 +146,7 @@ __global__ __launch_bounds__(kTPB, ((NW <= 4 && NWW <= 2) ? BC_MIN_WAVES : 1)) v
                                                            const uint16_t* __restrict__ lens, uint32_t stride,
                                                            uint32_t read_len, uint32_t nd, uint64_t n_reads,
                                                            uint32_t region, uint32_t* __restrict__ table,
+                                                           unsigned long long* __restrict__ slots, uint64_t smask,
                                                            unsigned long long* __restrict__ counters,
                                                            uint8_t* __restrict__ trace_outcome,
                                                            uint64_t* __restrict__ trace_idx) {
@@ -173,18 +188,26 @@ __global__ __launch_bounds__(kTPB, ((NW <= 4 && NWW <= 2) ? BC_MIN_WAVES : 1)) v
     const ReadResult r =
         process_read<DeviceOps, NW, NWW>(pl, ops, reinterpret_cast<const uint32_t*>(ops.tile), base, len, nd, active);
 
+    uint32_t outcome = r.outcome;
+    if (pl.has_random) {
+      // Results::add_count with a random barcode (info.rs:770-802): insert (tuple, random) into the
+      // set; an element already present makes the read a duplicate (parse.rs:65-69)
+      if (active && outcome == kMatched && !set_insert(slots, smask, r.dense_idx * pl.rspace + r.rcode))
+        outcome = kDuplicate;
+    } else if (active && outcome == kMatched && !pl.discard_counts && !(pl.ablate & 0x4u)) {
+      // Results::add_count (info.rs:761-767): one no-return atomic into the dense counter table
+      atomicAdd(&table[r.dense_idx], 1u);
+    }
     // outcome counters (SequenceErrors, info.rs:16-139)
 #pragma unroll
     for (uint32_t k = 0; k < BC_NCOUNTERS; ++k) {
-      if (k == BC_DUPLICATES || k == BC_TOTAL_READS) continue;
-      acc_cnt[k] += (uint32_t)__popcll(__ballot(active && r.outcome == k));
+      if (k == BC_TOTAL_READS) continue;
+      acc_cnt[k] += (uint32_t)__popcll(__ballot(active && outcome == k));
     }
     acc_cnt[BC_TOTAL_READS] += n_w;
-    // Results::add_count (info.rs:761-767): one no-return atomic into the dense counter table
-    if (active && r.outcome == kMatched && !pl.discard_counts && !(pl.ablate & 0x4u)) atomicAdd(&table[r.dense_idx], 1u);
     if (trace_outcome && active) {
-      trace_outcome[wfirst + lane] = (uint8_t)r.outcome;
-      trace_idx[wfirst + lane] = r.dense_idx;
+      trace_outcome[wfirst + lane] = (uint8_t)outcome;
+      trace_idx[wfirst + lane] = pl.has_random ? r.dense_idx * pl.rspace + r.rcode : r.dense_idx;
     }
   }
 
@@ -217,6 +240,54 @@ __global__ void build_dtable_kernel(const DevPlan* __restrict__ plp, uint32_t g,
 __global__ void fix_error_kernel(DevGroup G, uint32_t q1, uint32_t q2, uint32_t qn, uint32_t qx, uint32_t* out) {
   const uint32_t r = wave_fix_error(G, q1, q2, qn, qx, false);
   if (threadIdx.x == 0) *out = r;
+}
+
+__global__ void set_fill_kernel(unsigned long long* slots, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) slots[i] = kEmptyKey;
+}
+
+// re-inserts every key of `src` (n slots, or n plain keys when `dense`) into dst; counts the new ones
+__global__ void set_insert_kernel(const unsigned long long* __restrict__ src, uint64_t n, unsigned long long* dst,
+                                  uint64_t dmask, unsigned long long* n_new) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  uint32_t c = 0;
+  for (; i < n; i += step) {
+    const unsigned long long k = src[i];
+    if (k != kEmptyKey && set_insert(dst, dmask, k)) ++c;
+  }
+  if (n_new) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
+    if (__lane_id() == 0 && c) atomicAdd(n_new, (unsigned long long)c);
+  }
+}
+
+// compacts the keys of a set into out[0 .. *cursor)
+__global__ void set_export_kernel(const unsigned long long* __restrict__ slots, uint64_t n, unsigned long long* cursor,
+                                  unsigned long long* __restrict__ out, uint64_t capacity) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    const unsigned long long k = slots[i];
+    if (k != kEmptyKey) {
+      const unsigned long long p = atomicAdd(cursor, 1ull);
+      if (p < capacity) out[p] = k;
+    }
+  }
+}
+
+// final counts with a random barcode = number of distinct random barcodes per tuple (output.rs:265-270)
+__global__ void set_to_table_kernel(const unsigned long long* __restrict__ slots, uint64_t n, uint64_t rspace,
+                                    uint32_t* __restrict__ table) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    const unsigned long long k = slots[i];
+    if (k != kEmptyKey) atomicAdd(&table[k / rspace], 1u);
+  }
 }
 
 __global__ void count_nonzero_kernel(const uint32_t* __restrict__ table, uint64_t n, unsigned long long* total) {
@@ -311,6 +382,10 @@ struct bc_engine {
   size_t stage_bytes = 0;
   uint32_t lds_limit = 0;
   uint32_t n_cus = 0;
+  // random-barcode mode: the hash set of (tuple, random barcode) keys
+  unsigned long long* d_slots = nullptr;
+  uint64_t n_slots = 0;
+  uint64_t key_bound = 0;  // upper bound on the keys held: reads submitted / keys imported so far
 };
 
 static int upload(bc_engine* e, const void* src, size_t bytes, void** out) {
@@ -338,6 +413,7 @@ static void engine_free(bc_engine* e) {
   }
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->own_table && e->d_table) (void)hipFree(e->d_table);
+  if (e->d_slots) (void)hipFree(e->d_slots);
   if (e->d_counters) (void)hipFree(e->d_counters);
   if (e->d_plan) (void)hipFree(e->d_plan);
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
@@ -443,13 +519,38 @@ static int launch_match(bc_engine* e, const void* d_seq, const void* d_qual, con
   }
   hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(kTPB), lds, e->stream, e->d_plan, (const uint8_t*)d_seq,
                      (const uint8_t*)d_qual, (const uint16_t*)d_lens, stride, read_len, nd, n_reads, tile_alloc,
-                     e->d_table, e->d_counters, e->trace_outcome ? e->trace_outcome + trace_off : nullptr,
+                     e->d_table, e->d_slots, e->n_slots ? e->n_slots - 1 : 0, e->d_counters, e->trace_outcome ? e->trace_outcome + trace_off : nullptr,
                      e->trace_idx ? e->trace_idx + trace_off : nullptr);
   HIP_TRY(hipGetLastError());
   if (e->timing) {
     HIP_TRY(hipEventRecord(e1, e->stream));
     e->events.emplace_back(e0, e1);
   }
+  return BC_OK;
+}
+
+static uint32_t grid_for(uint64_t n) { return (uint32_t)std::min<uint64_t>((n + 255) / 256, 256ull * 32); }
+
+// Random-barcode mode: keeps the hash set at most half full for `more` further keys.  Growing
+// allocates a set of twice the size (or more) and re-inserts the old keys on the device.
+static int set_reserve(bc_engine* e, uint64_t more) {
+  if (!e->h.plan.has_random) return BC_OK;
+  e->key_bound += more;
+  uint64_t want = 1ull << 20;
+  while (want < 2 * e->key_bound) want <<= 1;
+  if (want <= e->n_slots) return BC_OK;
+  unsigned long long* fresh = nullptr;
+  HIP_TRY(hipMalloc((void**)&fresh, want * 8));
+  hipLaunchKernelGGL(set_fill_kernel, dim3(grid_for(want)), dim3(256), 0, e->stream, fresh, want);
+  if (e->d_slots) {
+    hipLaunchKernelGGL(set_insert_kernel, dim3(grid_for(e->n_slots)), dim3(256), 0, e->stream, e->d_slots, e->n_slots,
+                       fresh, want - 1, (unsigned long long*)nullptr);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    (void)hipFree(e->d_slots);
+  }
+  HIP_TRY(hipGetLastError());
+  e->d_slots = fresh;
+  e->n_slots = want;
   return BC_OK;
 }
 
@@ -475,6 +576,10 @@ static int submit_device_impl(bc_engine* e, const void* d_seq, const void* d_qua
   }
   const uint32_t nd = (maxlen + 3) / 4;
   HIP_TRY(hipSetDevice(e->device));
+  {
+    const int rc = set_reserve(e, n_reads);
+    if (rc != BC_OK) return rc;
+  }
   // candidate offsets 0 .. maxlen-L: how many 32-bit words the anchor / repair vectors need
   const uint32_t L = e->h.plan.L;
   const uint32_t nww = maxlen >= L ? (maxlen - L + 1 + 31) / 32 : 1;
@@ -595,6 +700,11 @@ int bc_engine_reset(bc_engine* e) {
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipMemsetAsync(e->d_table, 0, e->table_entries * 4, e->stream));
   HIP_TRY(hipMemsetAsync(e->d_counters, 0, BC_NCOUNTERS * 8, e->stream));
+  if (e->d_slots) {
+    hipLaunchKernelGGL(set_fill_kernel, dim3(grid_for(e->n_slots)), dim3(256), 0, e->stream, e->d_slots, e->n_slots);
+    HIP_TRY(hipGetLastError());
+  }
+  e->key_bound = 0;
   return BC_OK;
 }
 
@@ -618,6 +728,15 @@ int bc_engine_trace(bc_engine* e, void* d_outcome_u8, void* d_index_u64) {
 int bc_engine_finish(bc_engine* e, uint64_t* n_rows) {
   int rc = bc_engine_sync(e);
   if (rc) return rc;
+  if (e->h.plan.has_random) {
+    // the count of a tuple is the number of distinct random barcodes seen with it (output.rs:265-270)
+    HIP_TRY(hipMemsetAsync(e->d_table, 0, e->table_entries * 4, e->stream));
+    if (e->d_slots) {
+      hipLaunchKernelGGL(set_to_table_kernel, dim3(grid_for(e->n_slots)), dim3(256), 0, e->stream, e->d_slots,
+                         e->n_slots, e->h.plan.rspace, e->d_table);
+      HIP_TRY(hipGetLastError());
+    }
+  }
   unsigned long long* d_n = nullptr;
   HIP_TRY(hipMalloc((void**)&d_n, 16));
   HIP_TRY(hipMemsetAsync(d_n, 0, 16, e->stream));
@@ -665,6 +784,71 @@ int bc_engine_rows(bc_engine* e, uint64_t first, uint64_t n, uint32_t* sample_id
     sample_idx[r] = (uint32_t)di;
     count[r] = e->row_cnt[first + r];
   }
+  return BC_OK;
+}
+
+int bc_engine_key_count(bc_engine* e, uint64_t* n) {
+  *n = 0;
+  if (!e->h.plan.has_random || !e->d_slots) return BC_OK;
+  return bc_engine_export_keys(e, nullptr, 0, n);
+}
+
+int bc_engine_export_keys(bc_engine* e, void* d_keys, uint64_t capacity, uint64_t* n) {
+  *n = 0;
+  if (!e->h.plan.has_random) {
+    set_error("bc_engine_export_keys: the plan has no random barcode");
+    return BC_ERR_STATE;
+  }
+  int rc = bc_engine_sync(e);
+  if (rc) return rc;
+  if (!e->d_slots) return BC_OK;
+  unsigned long long* d_n = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_n, 8));
+  HIP_TRY(hipMemsetAsync(d_n, 0, 8, e->stream));
+  hipLaunchKernelGGL(set_export_kernel, dim3(grid_for(e->n_slots)), dim3(256), 0, e->stream, e->d_slots, e->n_slots, d_n,
+                     (unsigned long long*)d_keys, d_keys ? capacity : 0);
+  unsigned long long cnt = 0;
+  HIP_TRY(hipMemcpyAsync(&cnt, d_n, 8, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  (void)hipFree(d_n);
+  *n = cnt;
+  if (d_keys && cnt > capacity) {
+    set_error("bc_engine_export_keys: buffer too small");
+    return BC_ERR_INVALID;
+  }
+  return BC_OK;
+}
+
+int bc_engine_import_keys(bc_engine* e, const void* d_keys, uint64_t n, uint64_t* n_new) {
+  if (n_new) *n_new = 0;
+  if (!e->h.plan.has_random) {
+    set_error("bc_engine_import_keys: the plan has no random barcode");
+    return BC_ERR_STATE;
+  }
+  if (n == 0) return BC_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  int rc = set_reserve(e, n);
+  if (rc) return rc;
+  unsigned long long* d_n = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_n, 8));
+  HIP_TRY(hipMemsetAsync(d_n, 0, 8, e->stream));
+  hipLaunchKernelGGL(set_insert_kernel, dim3(grid_for(n)), dim3(256), 0, e->stream, (const unsigned long long*)d_keys, n,
+                     e->d_slots, e->n_slots - 1, d_n);
+  unsigned long long cnt = 0;
+  HIP_TRY(hipMemcpyAsync(&cnt, d_n, 8, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  (void)hipFree(d_n);
+  if (n_new) *n_new = cnt;
+  return BC_OK;
+}
+
+int bc_engine_clear_keys(bc_engine* e) {
+  HIP_TRY(hipSetDevice(e->device));
+  if (e->d_slots) {
+    hipLaunchKernelGGL(set_fill_kernel, dim3(grid_for(e->n_slots)), dim3(256), 0, e->stream, e->d_slots, e->n_slots);
+    HIP_TRY(hipGetLastError());
+  }
+  e->key_bound = 0;
   return BC_OK;
 }
 

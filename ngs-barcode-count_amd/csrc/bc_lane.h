@@ -553,6 +553,7 @@ BC_HD uint32_t single_n_lookup(const DevGroup& G, uint32_t q1, uint32_t q2, uint
 struct ReadResult {
   uint32_t outcome;    // Outcome; kMatched means "passed every test" (duplicate detection is later)
   uint64_t dense_idx;  // index into the dense (sample, tuple) counter table
+  uint64_t rcode;      // base-5 code of the random barcode (0 without one)
 };
 
 // Ops must provide:
@@ -568,6 +569,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
   ReadResult res;
   res.outcome = kMatched;
   res.dense_idx = 0;
+  res.rcode = 0;
 
   Planes<NW> P;
   uint32_t bad;
@@ -715,6 +717,19 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
         }
       }
     }
+  }
+  // ---- random barcode: kept as captured, never corrected (parse.rs:510-516) ------------------
+  if (pl.has_random) {
+    uint32_t r1, r2, rn;
+    extract_planes<NW>(P, pl.rnd_off, pl.rnd_len, r1, r2, rn);
+    const uint32_t rx = anyx ? extract_uniform<NW>(P.px, pl.rnd_off, pl.rnd_len) : 0u;
+    if (rx) unsupported = true;  // a byte outside ACGTN has no code
+    uint64_t code = 0;
+    for (uint32_t i = pl.rnd_len; i-- > 0;) {
+      const uint32_t d = ((rn >> i) & 1u) ? 4u : (((r1 >> i) & 1u) | (((r2 >> i) & 1u) << 1));
+      code = code * 5u + d;
+    }
+    res.rcode = code;
   }
   if (unsupported) outcome = kUnsupported;
   res.outcome = outcome;

@@ -147,10 +147,6 @@ bool bc_plan::lower(HostDevPlan& out) const {
     set_error("unsupported scheme: format length must be 1.." + std::to_string(kMaxNW * 32));
     return false;
   }
-  if (random_barcode) {
-    set_error("unsupported scheme: random barcode (PCR-duplicate collapse) needs the sparse key path, not built yet");
-    return false;
-  }
   if (sample_barcode && samples.size() == 0) {
     set_error("unsupported plan: sample barcode in the scheme without a sample barcode file (raw-key mode)");
     return false;
@@ -270,7 +266,8 @@ bool bc_plan::lower(HostDevPlan& out) const {
   out.n_samples = sample_barcode ? (uint32_t)samples.size() : 1u;
   // Results::add_count with a sample file but no sample group: the key "barcode" is absent, the
   // increment lands in a temporary, yet the read counts as matched (info.rs:762-766)
-  P.discard_counts = (!sample_barcode && samples.size() > 0) ? 1u : 0u;
+  // (with a random barcode the same call creates the "barcode" entry instead, info.rs:792-801)
+  P.discard_counts = (!sample_barcode && samples.size() > 0 && !random_barcode) ? 1u : 0u;
   unsigned __int128 entries = 1;
   for (int i = (int)order.size() - 1; i >= 0; --i) {
     const Pending& pd = order[i];
@@ -332,6 +329,25 @@ bool bc_plan::lower(HostDevPlan& out) const {
     }
   }
   out.table_entries = (uint64_t)entries;
+  if (random_barcode) {
+    for (const auto& g : groups) {
+      if (g.type != kGroupRandom) continue;
+      if (g.len == 0 || g.len > 27) {
+        set_error("unsupported scheme: random barcodes must be 1..27 bases");
+        return false;
+      }
+      unsigned __int128 space = 1;
+      for (uint32_t i = 0; i < g.len; ++i) space *= 5;
+      if (space * entries >= ((unsigned __int128)1 << 64) - 1) {
+        set_error("unsupported plan: (barcode tuple, random barcode) does not fit a 64-bit key");
+        return false;
+      }
+      P.has_random = 1;
+      P.rnd_off = g.off;
+      P.rnd_len = g.len;
+      P.rspace = (uint64_t)space;
+    }
+  }
   return true;
 }
 

@@ -28,3 +28,48 @@ def reduce_counters(counters, device, dst=0):
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM)
     return dict(zip(COUNTER_NAMES, [int(x) for x in t.tolist()]))
+
+
+# ---- random-barcode mode: counts are set sizes, so tables must not simply be summed -------------
+def key_owner(keys, world):
+    """owner rank of every 64-bit key (any well-mixed function works; it only has to be the same
+    on every rank)"""
+    h = keys * -7046029254386353131  # 0x9E3779B97F4A7C15 as int64; wraps
+    return ((h >> 33) & 0x7FFFFFFF) % world
+
+
+def exchange_keys(keys):
+    """all-to-all so that every key ends up on exactly one rank (duplicates across ranks meet on
+    their owner).  keys: int64 tensor of this rank's distinct keys -> int64 tensor received."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return keys
+    owner = key_owner(keys, world)
+    order = torch.argsort(owner)
+    keys = keys[order].contiguous()
+    send = torch.bincount(owner, minlength=world).to(torch.int64)
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send)
+    out = torch.empty(int(recv.sum().item()), dtype=torch.int64, device=keys.device)
+    dist.all_to_all_single(out, keys, recv.tolist(), send.tolist())
+    return out
+
+
+def finish_random(engine, device, dst=0):
+    """Global PCR-duplicate collapse: export this rank's keys, exchange them, keep
+    only the owned ones, fix the matched / duplicate counters, and leave per-tuple distinct counts
+    in the engine's table for reduce_table() + bc_engine_finish on the root.  Returns the global
+    counters on rank dst."""
+    local = engine.counters()
+    n = engine.key_count()
+    keys = torch.empty(max(n, 1), dtype=torch.int64, device=device)
+    engine.export_keys(keys.data_ptr(), n)
+    recv = exchange_keys(keys[:n])
+    engine.clear_keys()
+    owned = engine.import_keys(recv.data_ptr(), recv.numel()) if recv.numel() else 0
+    fixed = dict(local)
+    # every locally matched read is either the one owner-side survivor of its key or a duplicate
+    fixed["duplicates"] = local["duplicates"] + local["matched"] - owned
+    fixed["matched"] = owned
+    # (summed over ranks: matched = distinct keys overall, duplicates = all other passing reads)
+    return reduce_counters(fixed, device, dst=dst)

@@ -56,6 +56,7 @@ def build_case(name, seed=0, n=600):
         c["samples"] = {"AGCATAC": "Sample_name_1", "AACTTAC": "Sample_name_2"}
         c["counted"] = [["CAGAGAC", "TGATTGC"], ["ATGAAAT", "GCGCCAT"], ["GATAGCT", "TTAGCTA"]]
         c["kwargs"] = dict(min_quality=18.0)
+        # duplicates: same construct twice
         c["reads"] = readgen.gen_reads(rng, EXAMPLE_SCHEME, n, 78, ["AGCATACGGG", "AACTTACTTT"], c["counted"],
                                        p_sub=0.02, p_n=0.003)
     elif name == "crispr":
@@ -100,6 +101,13 @@ def build_case(name, seed=0, n=600):
         c["counted"] = [readgen.make_set(rng, 40, 8, 2) for _ in range(3)]
         c["reads"] = readgen.gen_reads(rng, DEL_SCHEME, n, 100, s, c["counted"], p_sub=0.01, p_n=0.002,
                                        p_other=0.01)
+    elif name == "example_files_random_nosample":
+        # random barcode, sample FILE given but no [n] group: the counts go under "barcode" (info.rs:792-801)
+        c["scheme"] = "AGCTACGAATCG{6}TGGA{6}TGGA{6}ACTAGAT(8)TAGA"
+        c["samples"] = {"AGCATAC": "Sample_name_1"}
+        c["counted"] = [["CAGAGA", "TGATTG"], ["ATGAAA", "GCGCCA"], ["GATAGC", "TTAGCT"]]
+        c["reads"] = readgen.gen_reads(rng, c["scheme"], n, 70, None, c["counted"], p_sub=0.01, p_n=0.004,
+                                       dup_frac=0.3)
     elif name == "long_gaps":
         c["scheme"] = GAP_SCHEME
         s = readgen.make_set(rng, 3, 32, 6)
@@ -114,4 +122,9 @@ def build_case(name, seed=0, n=600):
 
 ALL_CASES = ["del_exact", "del_mismatch_quality", "del_dense_ties", "del_random", "example_files",
              "example_files_samples", "crispr", "fmtn", "nosample_with_sample_file", "nosample",
-             "refs_with_n_and_ragged", "other_chars", "long_gaps"]
+             "refs_with_n_and_ragged", "other_chars", "long_gaps", "example_files_random_nosample"]
+
+RANDOM_CASES = ["del_random", "example_files", "example_files_samples", "example_files_random_nosample"]
+NO_RANDOM_CASES = [c for c in ALL_CASES if c not in RANDOM_CASES]
+# "example_files" has a sample group but no sample file: raw-key mode, which the engine refuses for now
+RANDOM_ENGINE_CASES = [c for c in RANDOM_CASES if c != "example_files"]

@@ -38,7 +38,7 @@ struct EmuPlan {
 
 template <int NW, int NWW>
 void run(const EmuPlan& E, const uint8_t* seq, const uint8_t* qual, const uint16_t* lens, uint32_t stride,
-         uint32_t read_len, uint64_t n, uint8_t* outcomes, uint64_t* idx) {
+         uint32_t read_len, uint64_t n, uint8_t* outcomes, uint64_t* idx, uint64_t* rcode) {
   const uint32_t maxlen = lens ? stride : read_len;
   const uint32_t nd = (maxlen + 3) / 4;
   HostOps ops;
@@ -55,6 +55,7 @@ void run(const EmuPlan& E, const uint8_t* seq, const uint8_t* qual, const uint16
     bc::ReadResult r = bc::process_read<HostOps, NW, NWW>(E.h.plan, ops, s32.data(), base, len, nd, true);
     outcomes[i] = (uint8_t)r.outcome;
     idx[i] = r.dense_idx;
+    if (rcode) rcode[i] = r.rcode;
   }
 }
 
@@ -93,14 +94,15 @@ void emu_plan_destroy(void* e) { delete (EmuPlan*)e; }
 
 uint64_t emu_table_entries(void* e) { return ((EmuPlan*)e)->h.table_entries; }
 int emu_discard_counts(void* e) { return (int)((EmuPlan*)e)->h.plan.discard_counts; }
+uint64_t emu_rspace(void* e) { return ((EmuPlan*)e)->h.plan.has_random ? ((EmuPlan*)e)->h.plan.rspace : 0; }
 
 int emu_process(void* e, const uint8_t* seq, const uint8_t* qual, const uint16_t* lens, uint32_t stride,
-                uint32_t read_len, uint64_t n, uint8_t* outcomes, uint64_t* idx) {
+                uint32_t read_len, uint64_t n, uint8_t* outcomes, uint64_t* idx, uint64_t* rcode) {
   const EmuPlan& E = *(EmuPlan*)e;
   const uint32_t maxlen = lens ? stride : read_len;
   const uint32_t L = E.h.plan.L;
   const uint32_t nww = maxlen >= L ? (maxlen - L + 1 + 31) / 32 : 1;
-#define EMU_RUN(NW_, NWW_) run<NW_, NWW_>(E, seq, qual, lens, stride, read_len, n, outcomes, idx)
+#define EMU_RUN(NW_, NWW_) run<NW_, NWW_>(E, seq, qual, lens, stride, read_len, n, outcomes, idx, rcode)
   if (maxlen <= 128) {
     if (nww <= 1) EMU_RUN(4, 1); else if (nww <= 2) EMU_RUN(4, 2); else EMU_RUN(4, 4);
   } else if (maxlen <= 256) {

@@ -30,7 +30,9 @@ def lib():
         L.emu_table_entries.restype = C.c_uint64
         L.emu_table_entries.argtypes = [C.c_void_p]
         L.emu_discard_counts.argtypes = [C.c_void_p]
-        L.emu_process.argtypes = [C.c_void_p] * 4 + [C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.emu_process.argtypes = [C.c_void_p] * 4 + [C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.emu_rspace.restype = C.c_uint64
+        L.emu_rspace.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -52,7 +54,9 @@ def make_plan(case):
     return p
 
 
-def emulate(plan, seq, qual, lens, stride, read_len):
+def emulate(plan, seq, qual, lens, stride, read_len, with_random=False):
+    """-> (outcomes, dense idx, table entries, discard flag); with_random adds (rcode, rspace): in
+    random-barcode mode outcome 0 means "passed every test" -- set membership is the caller's job"""
     L = lib()
     e = L.emu_plan_create(plan._p)
     if not e:
@@ -60,11 +64,15 @@ def emulate(plan, seq, qual, lens, stride, read_len):
     n = seq.size // stride
     outc = np.zeros(n, dtype=np.uint8)
     idx = np.zeros(n, dtype=np.uint64)
+    rcode = np.zeros(n, dtype=np.uint64)
     rc = L.emu_process(e, seq.ctypes.data, qual.ctypes.data if qual is not None else None,
                        lens.ctypes.data if lens is not None else None, stride, read_len, n, outc.ctypes.data,
-                       idx.ctypes.data)
+                       idx.ctypes.data, rcode.ctypes.data)
     entries = L.emu_table_entries(e)
     discard = L.emu_discard_counts(e)
+    rspace = L.emu_rspace(e)
     L.emu_plan_destroy(e)
     assert rc == 0
+    if with_random:
+        return outc, idx, entries, discard, rcode, rspace
     return outc, idx, entries, discard

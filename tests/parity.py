@@ -29,14 +29,34 @@ def decode_rows(plan, idx_counts, discard):
     return sorted(out)
 
 
-def check_per_read(case, plan, outcomes, idx, discard):
-    """outcomes/idx: per-read arrays from the engine; compares every read with the oracle"""
+def check_per_read(case, plan, outcomes, idx, discard, rspace=0):
+    """outcomes/idx: per-read arrays from the engine; compares every read with the oracle.
+    rspace > 0 (random-barcode plans): idx holds tuple_index * rspace + random code and a matched
+    read adds one distinct key to its tuple"""
     o = oracle_for(case)
     exp = [o.process(s, q) for s, q in case["reads"]]
     got_counts = {}
     for i, e in enumerate(exp):
         assert int(outcomes[i]) == CODE[e], (i, e, int(outcomes[i]), case["reads"][i])
         if e == "matched":
-            got_counts[int(idx[i])] = got_counts.get(int(idx[i]), 0) + 1
+            di = int(idx[i]) // rspace if rspace else int(idx[i])
+            got_counts[di] = got_counts.get(di, 0) + 1
     assert decode_rows(plan, got_counts, discard) == o.rows()
     return o
+
+
+def apply_set_semantics(outcomes, idx, rcode, rspace):
+    """host emulation only: turns "passed every test" into matched / duplicate by replaying the
+    reads in order against a set of (tuple, random barcode) keys; returns (outcomes, keys)"""
+    seen = set()
+    out = outcomes.copy()
+    keys = np.zeros(len(out), dtype=np.uint64)
+    for i in range(len(out)):
+        k = int(idx[i]) * int(rspace) + int(rcode[i])
+        keys[i] = k
+        if out[i] == 0:
+            if k in seen:
+                out[i] = CODE["duplicates"]
+            else:
+                seen.add(k)
+    return out, keys

@@ -82,3 +82,62 @@ def test_shards_tile_the_read_range():
             assert spans[0][0] == 0 and sum(c for _, c in spans) == n
             for (f0, c0), (f1, _) in zip(spans, spans[1:]):
                 assert f0 + c0 == f1
+
+
+def _worker_random(rank, world, port, out_path):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import emu_lib
+    import parity
+    import workloads
+    import ngs_barcode_count_amd as pkg
+    from ngs_barcode_count_amd import distributed as bcdist
+
+    n_total = 4000
+    w = workloads.make("config4", n_sets=(3, 6, 6, 6), n_molecules=1500)
+    first, count = bcdist.shard(n_total, rank, world)
+    seq, qual = w.synth.generate_host(first, count)
+    eplan = pkg.Plan(w.scheme, lib=emu_lib.lib())
+    for i, s in enumerate(w.samples):
+        eplan.add_sample(s, "sample_%d" % i)
+    for b, refs in enumerate(w.counted):
+        for i, s in enumerate(refs):
+            eplan.add_counted(b, s, "bb%d_%d" % (b + 1, i))
+    outc, idx, entries, discard, rcode, rspace = emu_lib.emulate(eplan, seq, qual, None, 100, 100, with_random=True)
+    out2, keys = parity.apply_set_semantics(outc, idx, rcode, rspace)  # this rank's local set semantics
+    local = {k: int((out2 == i).sum()) for i, k in enumerate(pkg.COUNTER_NAMES)}
+    local_keys = torch.from_numpy(np.unique(keys[out2 == 0]).astype(np.int64))
+    # the product's exchange: every key gets one owner; duplicates across ranks meet there
+    recv = bcdist.exchange_keys(local_keys)
+    owned = torch.unique(recv)  # what bc_engine_import_keys does on the device
+    assert bool((bcdist.key_owner(owned, world) == rank).all())
+    fixed = dict(local)
+    fixed["duplicates"] = local["duplicates"] + local["matched"] - owned.numel()
+    fixed["matched"] = owned.numel()
+    fixed["total_reads"], fixed["unsupported_reads"] = count, 0
+    total = bcdist.reduce_counters(fixed, torch.device("cpu"), dst=0)
+    table = torch.from_numpy(np.bincount((owned.numpy().astype(np.uint64) // np.uint64(rspace)).astype(np.int64),
+                                         minlength=entries).astype(np.int32))
+    bcdist.reduce_table(table, dst=0)
+    if rank == 0:
+        nz = torch.nonzero(table).flatten().numpy()
+        rows = parity.decode_rows(eplan, {int(i): int(table[i]) for i in nz}, False)
+        allseq, allqual = w.synth.generate_host(0, n_total)
+        o = workloads.oracle_for(w)
+        o.process_batch(allseq, allqual, 100, 100)
+        ok = rows == o.rows() and all(total[k] == v for k, v in o.counters.items())
+        with open(out_path, "w") as f:
+            f.write("ok" if ok and o.counters["duplicates"] > 500 else "MISMATCH %r vs %r" % (total, o.counters))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_random_barcode_key_exchange(tmp_path):
+    """PCR-duplicate collapse across ranks: a molecule sequenced on both ranks must count once"""
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_worker_random, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert open(out).read() == "ok"

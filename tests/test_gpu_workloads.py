@@ -41,6 +41,22 @@ def test_config_sample_vs_oracle(name, n):
     eng.close()
 
 
+def test_config4_random_barcode_vs_oracle():
+    """config 4 shape: DEL + 12-nt random barcode, molecules drawn with repeats (mean 2 per molecule)"""
+    n = 150000
+    w = workloads.make("config4", n_molecules=n // 2)
+    eng = _run(w, 0, n, chunk=40000)  # several submits: the hash set grows across batches
+    seq, qual = w.synth.generate_host(0, n)
+    o = workloads.oracle_for(w)
+    o.process_batch(seq, qual, w.read_len, w.read_len)
+    got = eng.counters()
+    for k, v in o.counters.items():
+        assert got[k] == v, (k, got, o.counters)
+    assert got["duplicates"] > n // 4
+    assert eng.result_rows() == o.rows()
+    eng.close()
+
+
 def test_synth_device_equals_host():
     import torch
     w = workloads.make("config3", n_sets=(4, 100, 100, 100))

@@ -10,7 +10,7 @@ import emu_lib
 import parity
 import readgen
 
-NO_RANDOM = [c for c in cases.ALL_CASES if c not in ("del_random", "example_files", "example_files_samples")]
+NO_RANDOM = cases.NO_RANDOM_CASES
 
 
 @pytest.mark.parametrize("name", NO_RANDOM)
@@ -27,6 +27,22 @@ def test_lane_code_vs_oracle(name, use_lens):
     outc, idx, entries, discard = emu_lib.emulate(plan, seq.reshape(-1), qual.reshape(-1), lens if use_lens else None,
                                                   stride, stride)
     parity.check_per_read(c, plan, outc, idx, discard)
+
+
+@pytest.mark.parametrize("name", cases.RANDOM_ENGINE_CASES)
+def test_random_barcode_keys_vs_oracle(name):
+    """random-barcode schemes: the lane code's (tuple, random) key + set semantics vs the oracle's
+    duplicate collapse (info.rs:770-802)"""
+    c = cases.build_case(name, seed=7, n=700)
+    plan = emu_lib.make_plan(c)
+    seq, qual, lens = readgen.to_arrays(c["reads"])
+    stride = seq.shape[1]
+    outc, idx, entries, discard, rcode, rspace = emu_lib.emulate(plan, seq.reshape(-1), qual.reshape(-1), lens, stride,
+                                                                 stride, with_random=True)
+    assert rspace in (5 ** 8, 5 ** 12)
+    out2, keys = parity.apply_set_semantics(outc, idx, rcode, rspace)
+    o = parity.check_per_read(c, plan, out2, keys, discard, rspace)
+    assert name == "example_files_samples" or o.counters["duplicates"] > 0
 
 
 def test_long_reads_use_wider_planes():

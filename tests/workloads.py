@@ -12,7 +12,7 @@ class Workload:
     pass
 
 
-def make(name, n_sets=None, lib=None):
+def make(name, n_sets=None, lib=None, n_molecules=None):
     """name: config2 | config3 | config5.  n_sets = (samples, refs per counted barcode...) overrides the
     BASELINE sizes (tests use smaller sets so the CPU oracle stays fast)."""
     w = Workload()
@@ -40,6 +40,21 @@ def make(name, n_sets=None, lib=None):
             plan.set_min_quality(20.0)
             w.synth_args = dict(seed=3, p_sub=0.01, p_n=0.001, p_lowq=0.05)
             w.min_quality = 20.0
+    elif name == "config4":
+        # DEL + 12-nt random barcode, PCR duplicates: reads are draws from n_molecules molecules
+        sizes = n_sets or (4, 1000, 1000, 1000)
+        w.scheme = DEL_RANDOM_SCHEME
+        plan = pkg.Plan(w.scheme, lib=lib)
+        w.samples = pkg.make_set(SET_SEED, sizes[0], 8, 3, lib=lib)
+        w.counted = [pkg.make_set(SET_SEED + 1 + i, sizes[1 + i], 8, 2, lib=lib) for i in range(3)]
+        for i, s in enumerate(w.samples):
+            plan.add_sample(s, "sample_%d" % i)
+        for b, refs in enumerate(w.counted):
+            for i, s in enumerate(refs):
+                plan.add_counted(b, s, "bb%d_%d" % (b + 1, i))
+        w.kwargs = {}
+        w.synth_args = dict(seed=4, p_sub=0.01, p_n=0.001, n_molecules=n_molecules or 200_000_000)
+        w.min_quality = 0.0
     elif name == "config5":
         sizes = n_sets or (100000,)
         w.scheme = CRISPR_SCHEME
@@ -66,4 +81,5 @@ def oracle_for(w):
 
 def bytes_per_read(w, f_matched):
     """algorithmic bytes per read, SURVEY.md 8(d): R + (R if quality filter) + 8 * f_matched"""
+    # (random-barcode mode: one 8-byte key insert instead of the 8-byte counter read-modify-write)
     return w.read_len * (2 if w.min_quality > 0 else 1) + 8.0 * f_matched
