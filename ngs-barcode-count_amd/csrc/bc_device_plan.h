@@ -47,6 +47,16 @@ struct DevGroup {
   const uint8_t* rlen;    // reference length
   const uint64_t* hkeys;  // kSetHash: q1 | q2 << 32 of references usable for exact lookup
   const uint32_t* hvals;  // index or kFail for an empty slot
+  // kSetHash, large sets: pigeonhole seeds.  The capture is cut into seed_nb = max_err + 1 blocks of
+  // seed_blen bases; a reference within max_err mismatches equals the capture on at least one block,
+  // so only the references filed under the capture's block values need scoring.
+  uint32_t seed_nb;       // 0: no seed index, score every reference
+  uint32_t seed_blen;
+  uint32_t n_idx;         // plain references (no 'N', length == len) in the index
+  uint32_t n_odd;         // the others, always scored
+  const uint32_t* seed_off;   // [seed_nb][4^seed_blen + 1] bucket starts into seed_list rows
+  const uint32_t* seed_list;  // [seed_nb][n_idx] entries {r1, r2, index, 0} (16 B) ordered by block value
+  const uint32_t* odd_list;   // [n_odd]
 };
 
 struct DevPlan {

@@ -37,6 +37,17 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
   return v;
 }
 
+// combines the lanes' partial unique-minimum searches: wave min-reduce of the key, then a vote
+__device__ __forceinline__ uint32_t wave_verdict(const Nearest& s, uint32_t max_err) {
+  const uint32_t kmin = wave_min_u32(s.key);
+  const unsigned long long holders = __ballot(s.key == kmin);
+  const int first = __ffsll(holders) - 1;
+  const uint32_t cnt = (uint32_t)__shfl((int)s.count, first);
+  const uint32_t idx = (uint32_t)__shfl((int)s.idx, first);
+  const bool unique = __popcll(holders) == 1 && kmin != 0xFFFFFFFFu;
+  return unique ? nearest_result(kmin, idx, cnt, max_err) : kFail;
+}
+
 // fix_error (parse.rs:553-593) for ONE capture by the whole wavefront: every lane scores the
 // references j = lane, lane+64, ...; a wavefront min-reduce plus a vote decides best / ambiguous.
 // use_exact: a reference that IS the capture wins outright (AHashSet::contains, parse.rs:457/489).
@@ -50,13 +61,103 @@ __device__ __forceinline__ uint32_t wave_fix_error(const DevGroup& G, uint32_t q
     const uint32_t d = ref_distance(q1, q2, qn, qx, G.len, G.r1[j], G.r2[j], G.rn[j], G.rlen[j], ex);
     nearest_add(s, d, j, ex && use_exact);
   }
+  return wave_verdict(s, G.max_err);
+}
+
+// The same verdict for a large set through the pigeonhole seed index: only references that equal
+// the capture on one of its max_err+1 blocks can be within the budget, and every reference within
+// the budget is among them, so best / ambiguous come out exactly as from the full scan.
+// The whole wavefront walks the capture's buckets, 256 entries (four 1-KiB loads) in flight; the
+// entries carry the reference planes, so there is one memory round trip per batch.
+// The capture must be free of 'N' / foreign bytes.
+// Returns the smallest key (distance + 1, 0 for the capture itself), whether exactly one reference
+// has it, and that reference.
+__device__ __forceinline__ void wave_seeded_min(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t& kmin_out,
+                                                bool& unique_out, uint32_t& idx_out) {
+  const uint32_t nb = G.seed_nb, blen = G.seed_blen, bm = (1u << blen) - 1u;
+  const uint32_t nbk = 1u << (2 * blen);
+  const uint32_t lane = __lane_id();
+  const uint4* entries = reinterpret_cast<const uint4*>(G.seed_list);
+  Nearest s;
+  nearest_init(s);
+  for (uint32_t b = 0; b < nb; ++b) {
+    const uint32_t val = ((q1 >> (b * blen)) & bm) | (((q2 >> (b * blen)) & bm) << blen);
+    const uint32_t* off = G.seed_off + (size_t)b * (nbk + 1);
+    const uint32_t beg = off[val], end = off[val + 1];
+    const uint4* list = entries + (size_t)b * G.n_idx;
+    // blocks before b on which a reference may not equal the capture (it was scored there)
+    for (uint32_t i0 = beg; i0 < end; i0 += 256) {
+      uint4 e[4];
+      bool on[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t i = i0 + 64u * k + lane;
+        on[k] = i < end;
+        e[k] = list[on[k] ? i : beg];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t diff = (q1 ^ e[k].x) | (q2 ^ e[k].y);
+        bool earlier = false;
+        for (uint32_t p = 0; p < b; ++p) earlier = earlier || ((diff >> (p * blen)) & bm) == 0u;
+        if (on[k] && !earlier) nearest_add(s, popc(diff), e[k].z, diff == 0u);
+      }
+    }
+    // A reference with d mismatches has at most d spoiled blocks, so it has shown up by the time
+    // blocks 0..d are done: once the best distance so far is <= b nothing nearer or equally near
+    // can still be hiding in the later blocks.
+    const uint32_t kmin = wave_min_u32(s.key);
+    if (kmin != 0xFFFFFFFFu && kmin <= b + 1u) break;
+  }
+  for (uint32_t i = lane; i < G.n_odd; i += 64) {
+    const uint32_t j = G.odd_list[i];
+    bool ex;
+    const uint32_t d = ref_distance(q1, q2, 0u, 0u, G.len, G.r1[j], G.r2[j], G.rn[j], G.rlen[j], ex);
+    nearest_add(s, d, j, ex);
+  }
   const uint32_t kmin = wave_min_u32(s.key);
   const unsigned long long holders = __ballot(s.key == kmin);
   const int first = __ffsll(holders) - 1;
-  const uint32_t cnt = (uint32_t)__shfl((int)s.count, first);
-  const uint32_t idx = (uint32_t)__shfl((int)s.idx, first);
-  const bool unique = __popcll(holders) == 1 && kmin != 0xFFFFFFFFu;
-  return unique ? nearest_result(kmin, idx, cnt, G.max_err) : kFail;
+  kmin_out = kmin;
+  unique_out = __popcll(holders) == 1 && (uint32_t)__shfl((int)s.count, first) == 1u && kmin != 0xFFFFFFFFu;
+  idx_out = (uint32_t)__shfl((int)s.idx, first);
+}
+
+// A capture with up to two 'N's against plain references: 'N' is free (parse.rs:569), so its
+// distance to a reference is that of the capture with each N replaced by the reference's base
+// there.  The nearest references of the capture are therefore those of its 4 (16) substitutions
+// at the smallest of their minimum distances, and the match is unique iff exactly one substitution
+// reaches that distance and does so uniquely (the argument of single_n_lookup, bc_lane.h).
+__device__ __forceinline__ uint32_t wave_fix_error_seeded(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t qn) {
+  const uint32_t n_n = popc(qn);
+  const uint32_t p0 = n_n ? ctz(qn) : 0u;
+  const uint32_t p1 = n_n > 1 ? ctz(qn & (qn - 1u)) : 0u;
+  const uint32_t combos = 1u << (2u * n_n);
+  const uint32_t b1 = q1 & ~qn, b2 = q2 & ~qn;
+  uint32_t best = 0xFFFFFFFFu, res = kFail;
+  bool ok = false;
+  for (uint32_t c = 0; c < combos; ++c) {
+    uint32_t s1 = b1, s2 = b2;
+    if (n_n > 0) {
+      s1 |= (c & 1u) << p0;
+      s2 |= ((c >> 1) & 1u) << p0;
+    }
+    if (n_n > 1) {
+      s1 |= ((c >> 2) & 1u) << p1;
+      s2 |= ((c >> 3) & 1u) << p1;
+    }
+    uint32_t k, idx;
+    bool uniq;
+    wave_seeded_min(G, s1, s2, k, uniq, idx);
+    if (k < best) {
+      best = k;
+      ok = uniq;
+      res = idx;
+    } else if (k == best) {
+      ok = false;
+    }
+  }
+  return (ok && best != 0xFFFFFFFFu && (best == 0u || best - 1u <= G.max_err)) ? res : kFail;
 }
 
 // Wave-private LDS tile: each wavefront stages the 64 reads it owns (64*stride contiguous bytes of
@@ -120,8 +221,8 @@ struct DeviceOps {
   // every lane calls this; lanes with `need` get their capture resolved one after the other
   __device__ __forceinline__ uint32_t nearest(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t qn, uint32_t qx,
                                               bool need) const {
-    unsigned long long todo = __ballot(need);
     uint32_t out = kFail;
+    unsigned long long todo = __ballot(need);
     while (todo) {
       const int src = __ffsll(todo) - 1;
       todo &= todo - 1;
@@ -129,7 +230,9 @@ struct DeviceOps {
       const uint32_t b2 = (uint32_t)__shfl((int)q2, src);
       const uint32_t bn = (uint32_t)__shfl((int)qn, src);
       const uint32_t bx = (uint32_t)__shfl((int)qx, src);
-      const uint32_t r = wave_fix_error(G, b1, b2, bn, bx, true);
+      // the seed index answers captures with at most two 'N's when every reference is plain
+      const bool seeded = G.seed_nb && bx == 0u && G.n_odd == 0u && __popc(bn) <= 2;
+      const uint32_t r = seeded ? wave_fix_error_seeded(G, b1, b2, bn) : wave_fix_error(G, b1, b2, bn, bx, true);
       if (lane == (uint32_t)src) out = r;
     }
     return out;
@@ -459,6 +562,11 @@ static int engine_init(bc_engine* e, const bc_plan* p, int device_id, void* hip_
     if (G.mode == kSetHash) {
       if ((rc = upload(e, H.hkeys.data(), H.hkeys.size() * 8, (void**)&G.hkeys))) return rc;
       if ((rc = upload(e, H.hvals.data(), H.hvals.size() * 4, (void**)&G.hvals))) return rc;
+      if (G.seed_nb) {
+        if ((rc = upload(e, H.seed_off.data(), H.seed_off.size() * 4, (void**)&G.seed_off))) return rc;
+        if ((rc = upload(e, H.seed_list.data(), H.seed_list.size() * 4, (void**)&G.seed_list))) return rc;
+        if ((rc = upload(e, H.odd_list.data(), H.odd_list.size() * 4, (void**)&G.odd_list))) return rc;
+      }
     }
     if (G.mode == kSetDirect) {
       void* d = nullptr;

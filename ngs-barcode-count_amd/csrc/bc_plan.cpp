@@ -326,6 +326,40 @@ bool bc_plan::lower(HostDevPlan& out) const {
         H.hkeys[h] = key;
         H.hvals[h] = j;
       }
+      // pigeonhole seed index (see bc_device_plan.h)
+      const uint32_t nb = G.max_err + 1;
+      uint32_t blen = G.len / nb;
+      if (blen > 8) blen = 8;
+      if (G.n_refs >= 128 && blen >= 3) {
+        std::vector<uint32_t> plain;
+        for (uint32_t j = 0; j < G.n_refs; ++j) {
+          if (H.rn[j] || H.rlen[j] != G.len)
+            H.odd_list.push_back(j);
+          else
+            plain.push_back(j);
+        }
+        const uint32_t nbk = 1u << (2 * blen);
+        const uint32_t bm = (1u << blen) - 1;
+        H.seed_off.assign((size_t)nb * (nbk + 1), 0);
+        H.seed_list.assign((size_t)nb * plain.size() * 4, 0);
+        for (uint32_t b = 0; b < nb; ++b) {
+          auto value = [&](uint32_t j) { return ((H.r1[j] >> (b * blen)) & bm) | (((H.r2[j] >> (b * blen)) & bm) << blen); };
+          uint32_t* off = &H.seed_off[(size_t)b * (nbk + 1)];
+          for (uint32_t j : plain) off[value(j) + 1]++;
+          for (uint32_t v = 0; v < nbk; ++v) off[v + 1] += off[v];
+          std::vector<uint32_t> cur(off, off + nbk);
+          for (uint32_t j : plain) {
+            uint32_t* e = &H.seed_list[((size_t)b * plain.size() + cur[value(j)]++) * 4];
+            e[0] = H.r1[j];
+            e[1] = H.r2[j];
+            e[2] = j;
+          }
+        }
+        G.seed_nb = nb;
+        G.seed_blen = blen;
+        G.n_idx = (uint32_t)plain.size();
+        G.n_odd = (uint32_t)H.odd_list.size();
+      }
     }
   }
   out.table_entries = (uint64_t)entries;
