@@ -169,6 +169,19 @@ int bc_engine_kernel_ms(bc_engine *e, double *total_ms, uint64_t *launches);
 int64_t bc_fix_error(const char *mismatch_seq, const char *const *possible_seqs, uint64_t n, uint16_t mismatches,
                      int device_id);
 
+/* ---- FASTQ ingest (replaces input::read_fastq, input.rs:24-149) --------------- */
+
+/* Reads a whole *.fastq / *.fastq.gz file, frames it into 4-line records exactly as
+ * FastqLineReader does (input.rs:115-148), and submits the sequence / quality lines to the engine in
+ * batches through bc_engine_submit_host (pinned buffers, copies overlapped with the kernel).
+ * *total_reads receives the reference's "Total sequences" value, including its quirks: a trailing
+ * partial record is counted but never processed, and a .gz input counts one read more
+ * (input.rs:69-73, 128-130).  progress (may be NULL) is called with the running total about every
+ * million reads.  Errors the reference raises come back as BC_ERR_INVALID with its message:
+ * wrong extension (input.rs:36-39), unreadable file, first record not FASTQ (parse.rs:377-394). */
+typedef void (*bc_progress_fn)(uint64_t total_reads, void *user);
+int bc_fastq_count(bc_engine *e, const char *fastq_path, uint64_t *total_reads, bc_progress_fn progress, void *user);
+
 /* ---- synthetic workloads (bench + full-size parity) -------------------------------------- */
 
 typedef struct bc_synth_params {

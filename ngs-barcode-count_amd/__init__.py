@@ -150,6 +150,13 @@ class Engine:
             lp = lens.ctypes.data
         _check(self._lib, self._lib.bc_engine_submit_host(self._e, seq.ctypes.data, qp, lp, stride, read_len, n))
 
+    def count_fastq(self, path):
+        """input::read_fastq + the workers (input.rs:24-89, parse.rs:53-76): reads a .fastq / .fastq.gz
+        file and counts it; returns the reference's "Total sequences" value"""
+        n = C.c_uint64()
+        _check(self._lib, self._lib.bc_fastq_count(self._e, str(path).encode(), C.byref(n), None, None))
+        return n.value
+
     def sync(self):
         _check(self._lib, self._lib.bc_engine_sync(self._e))
 

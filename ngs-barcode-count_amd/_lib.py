@@ -77,6 +77,7 @@ ENGINE_API = {
     "bc_engine_import_keys": (_int, [_vp, _vp, _u64, C.POINTER(C.c_uint64)]),
     "bc_engine_clear_keys": (_int, [_vp]),
     "bc_fix_error": (C.c_int64, [_cp, C.POINTER(_cp), _u64, C.c_uint16, _int]),
+    "bc_fastq_count": (_int, [_vp, _cp, C.POINTER(C.c_uint64), _vp, _vp]),
     "bc_synth_create": (_vp, [_vp, C.POINTER(SynthParams)]),
     "bc_synth_destroy": (None, [_vp]),
     "bc_synth_generate_host": (_int, [_vp, _u64, _u64, _vp, _vp, _u32]),

@@ -1,0 +1,150 @@
+"""End-to-end drop-in check of the `barcode-count` command line (FASTQ ingest -> gfx950 engine ->
+CSV / stats writers) against the oracle's counts pushed through an independent restatement of the
+reference's writers (tests/pyref_output.py)."""
+import gzip
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import cases
+import parity
+import pyref_output
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "ngs-barcode-count_amd", "csrc", "barcode-count")
+
+
+def write_inputs(tmp, c, gz=False, crlf=False):
+    nl = "\r\n" if crlf else "\n"
+    fq = os.path.join(tmp, "reads.fastq" + (".gz" if gz else ""))
+    text = "".join("@read_%d some description%s%s%s+%s%s%s" % (i, nl, s, nl, nl, q, nl) for i, (s, q) in enumerate(c["reads"]))
+    if gz:
+        with gzip.open(fq, "wt", newline="") as f:
+            f.write(text)
+    else:
+        with open(fq, "w", newline="") as f:
+            f.write(text)
+    scheme = os.path.join(tmp, "scheme.txt")
+    open(scheme, "w").write("# test scheme\n" + c["scheme"] + "\n")
+    args = ["-f", fq, "-q", scheme]
+    if c.get("samples"):
+        p = os.path.join(tmp, "samples.csv")
+        open(p, "w").write("Barcode,Sample_ID\n" + "".join("%s,%s\n" % kv for kv in c["samples"].items()))
+        args += ["-s", p]
+    if c.get("counted"):
+        p = os.path.join(tmp, "counted.csv")
+        open(p, "w").write("Barcode,Barcode_ID,Barcode_Number\n" + "".join(
+            "%s,bb%d_%s,%d\n" % (s, b + 1, s, b + 1) for b, refs in enumerate(c["counted"]) for s in refs))
+        args += ["-c", p]
+    kw = c.get("kwargs", {})
+    for flag, key in (("--max-errors-sample", "max_sample"), ("--max-errors-counted-barcode", "max_barcode"),
+                      ("--max-errors-constant", "max_constant"), ("--min-quality", "min_quality")):
+        if kw.get(key) is not None:
+            args += [flag, str(kw[key])]
+    return args
+
+
+def expected(c, prefix, merge, enrich):
+    o = parity.oracle_for(c)
+    for s, q in c["reads"]:
+        o.process(s, q)
+    results = {k: {} for k in o.sample_keys()}
+    for s, t, n in o.rows():
+        results.setdefault(s, {})[t] = n
+    counted_hash = [{s: "bb%d_%s" % (b + 1, s) for s in refs} for b, refs in enumerate(c["counted"])] if c.get("counted") else []
+    barcode_num = len(c["counted"]) if c.get("counted") else 0
+    w = pyref_output.Writer(results, dict(c["samples"] or {}), counted_hash, barcode_num, prefix, merge, enrich).write()
+    return o, w
+
+
+def read_csv(path):
+    lines = open(path).read().split("\n")
+    assert lines[-1] == ""
+    return lines[0], sorted(lines[1:-1])
+
+
+@pytest.mark.parametrize("name,merge,enrich,gz", [("del_mismatch_quality", True, True, False),
+                                                   ("del_random", True, False, True),
+                                                   ("nosample", False, True, False),
+                                                   ("crispr", True, True, False),
+                                                   ("example_files_random_nosample", True, True, False),
+                                                   ("nosample_with_sample_file", False, False, False)])
+def test_cli_outputs(tmp_path, name, merge, enrich, gz):
+    c = cases.build_case(name, seed=31, n=2500)
+    tmp = str(tmp_path)
+    args = write_inputs(tmp, c, gz=gz)
+    out = os.path.join(tmp, "out")
+    os.makedirs(out)
+    cmd = [CLI] + args + ["-o", out, "-p", "run1"] + (["-m"] if merge else []) + (["-e"] if enrich else [])
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr + res.stdout
+    o, w = expected(c, "run1", merge, enrich)
+    produced = sorted(f for f in os.listdir(out) if f.endswith(".csv"))
+    assert produced == sorted(w.files), (produced, sorted(w.files))
+    for fn, (header, rows) in w.files.items():
+        h, r = read_csv(os.path.join(out, fn))
+        assert h == header, fn
+        assert r == rows, fn
+    # stdout / stats: counters, total sequences (gz counts one more, input.rs:69-73), files and counts
+    total = len(c["reads"]) + (1 if gz else 0)
+    assert ("Total sequences:             {:,}".format(total)) in res.stdout
+    stats = open(os.path.join(out, "run1_barcode_stats.txt")).read()
+    for label, key in (("Correctly matched sequences: ", "matched"), ("Constant region mismatches:  ", "constant_region"),
+                       ("Sample barcode mismatches:   ", "sample_barcode"), ("Counted barcode mismatches:  ", "barcode"),
+                       ("Duplicates:                  ", "duplicates"), ("Low quality barcodes:        ", "low_quality")):
+        line = label + "{:,}".format(o.counters[key])
+        assert line in res.stdout and line in stats, line
+    listed = re.findall(r"File & barcodes counted: (\S+)\t([\d,]+)", stats)
+    assert [f for f, _ in listed] == w.output_files
+    assert [int(n.replace(",", "")) for _, n in listed] == w.output_counts
+    assert stats.startswith("-TIME INFORMATION-\nStart: ") and "-FORMAT-\n" + o.format_string in stats
+    assert "-BARCODE INFO-\nConstant region size: %d\n" % o.constant_region_length in stats
+
+
+def test_cli_appends_stats_and_rejects_bad_input(tmp_path):
+    c = cases.build_case("del_exact", seed=32, n=300)
+    tmp = str(tmp_path)
+    args = write_inputs(tmp, c, crlf=True)  # CRLF line ends are stripped on the plain path (input.rs:44)
+    for _ in range(2):
+        res = subprocess.run([CLI] + args + ["-o", tmp, "-p", "p"], capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr
+    assert open(os.path.join(tmp, "p_barcode_stats.txt")).read().count("-TIME INFORMATION-") == 2
+    o, w = expected(c, "p", False, False)
+    for fn, (header, rows) in w.files.items():
+        assert read_csv(os.path.join(tmp, fn)) == (header, rows)
+    bad = os.path.join(tmp, "reads.txt")
+    open(bad, "w").write("x")
+    res = subprocess.run([CLI, "-f", bad, "-q", args[3]] + args[4:], capture_output=True, text=True)
+    assert res.returncode != 0 and "only works with *.fastq" in res.stderr
+    fq = os.path.join(tmp, "swapped.fastq")
+    open(fq, "w").write("ACGTACGTACGT\n@name\n+\nIIIIIIIIIIII\n")
+    res = subprocess.run([CLI, "-f", fq, "-q", args[3]] + args[4:], capture_output=True, text=True)
+    assert res.returncode != 0 and "first line within the FASTQ contains DNA" in res.stderr
+
+
+def test_count_fastq_through_the_abi(tmp_path):
+    import ngs_barcode_count_amd as pkg
+    from test_gpu_parity import make_plan
+    c = cases.build_case("fmtn", seed=33, n=1500)  # ragged read lengths
+    args = write_inputs(str(tmp_path), c)
+    plan = make_plan(c)
+    eng = pkg.Engine(plan, device=0)
+    assert eng.count_fastq(args[1]) == len(c["reads"])
+    o = parity.oracle_for(c)
+    for s, q in c["reads"]:
+        o.process(s, q)
+    got = eng.counters()
+    assert {k: got[k] for k in o.counters} == o.counters and eng.result_rows() == o.rows()
+    # a trailing partial record is counted but never processed
+    with open(args[1], "a") as f:
+        f.write("@partial\nACGT\n")
+    e2 = pkg.Engine(plan, device=0)
+    assert e2.count_fastq(args[1]) == len(c["reads"]) + 1
+    assert e2.counters()["total_reads"] == len(c["reads"])
+    eng.close()
+    e2.close()
