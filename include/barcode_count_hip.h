@@ -142,6 +142,16 @@ int bc_engine_finish(bc_engine *e, uint64_t *n_rows);
 int bc_engine_rows(bc_engine *e, uint64_t first, uint64_t n, uint32_t *sample_idx, uint32_t *barcode_idx,
                    uint64_t *count);
 
+/* Row i as the reference's Results holds it (info.rs:661-665): the sample key (a sample barcode
+ * sequence, or "barcode" without a sample group) and the counted barcodes "b1,b2,.." as sequences.
+ * Works for every plan, including those that keep raw captures (no sample / counted-barcode
+ * file: README.md "Barcode-seq"), whose rows have no index form. */
+int bc_engine_row_text(bc_engine *e, uint64_t row, char *sample, size_t sample_cap, char *tuple, size_t tuple_cap,
+                       uint64_t *count);
+/* 0: the engine cannot run the plan (bc_last_error says why); 1: dense counter table;
+ * 2: hash map of tuple keys (some barcode is kept raw because no conversion file names it) */
+int bc_plan_mode(const bc_plan *p);
+
 /* Random-barcode schemes (PCR-duplicate collapse, Results::add_count info.rs:770-802): the engine
  * keeps the set of distinct (sample, barcode tuple, random barcode) keys in a device hash set; a
  * read whose key is already present counts as BC_DUPLICATES (parse.rs:65-69) and the count of a

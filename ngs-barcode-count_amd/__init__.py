@@ -109,11 +109,18 @@ class Plan:
         return self._lib.bc_plan_quality_threshold(self._p, run_len)
 
     @property
-    def table_entries(self):
-        n = self._lib.bc_plan_table_entries(self._p)
-        if n == 0:
+    def mode(self):
+        """"dense" (counter table) or "sparse" (hash map of tuple keys: some barcode is kept raw)"""
+        m = self._lib.bc_plan_mode(self._p)
+        if m == 0:
             raise BarcodeCountError(_lib.BC_ERR_UNSUPPORTED, _lib.last_error(self._lib))
-        return n
+        return "dense" if m == 1 else "sparse"
+
+    @property
+    def table_entries(self):
+        if self.mode == "sparse":
+            return 0
+        return self._lib.bc_plan_table_entries(self._p)
 
 
 class Engine:
@@ -218,6 +225,15 @@ class Engine:
 
     def result_rows(self):
         """sorted [(sample key, "b1,b2,..", count)] with sequences as keys, like Results (info.rs:661-665)"""
+        if self.plan.mode == "sparse":
+            n = C.c_uint64()
+            _check(self._lib, self._lib.bc_engine_finish(self._e, C.byref(n)))
+            sb, tb, cnt = C.create_string_buffer(64), C.create_string_buffer(1024), C.c_uint64()
+            out = []
+            for i in range(n.value):
+                _check(self._lib, self._lib.bc_engine_row_text(self._e, i, sb, 64, tb, 1024, C.byref(cnt)))
+                out.append((sb.value.decode(), tb.value.decode(), int(cnt.value)))
+            return sorted(out)
         s, b, c = self.rows()
         samples = [x for x, _ in self.plan.samples()] if self.plan.sample_barcode else ["barcode"]
         sets = [[x for x, _ in self.plan.counted(i)] for i in range(self.plan.barcode_num)]

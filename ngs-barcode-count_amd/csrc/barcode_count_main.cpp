@@ -600,20 +600,17 @@ int main(int argc, char** argv) {
   if (r.samples.empty() && !sample_group) r.sample_keys.push_back("barcode");
   uint64_t n_rows = 0;
   if (bc_engine_finish(r.engine, &n_rows)) die("%s", bc_last_error());
-  {
-    const uint32_t nb = r.barcode_num ? r.barcode_num : 1;
-    std::vector<uint32_t> sidx(n_rows ? n_rows : 1), bidx((n_rows ? n_rows : 1) * nb);
-    std::vector<uint64_t> cnt(n_rows ? n_rows : 1);
-    if (n_rows && bc_engine_rows(r.engine, 0, n_rows, sidx.data(), bidx.data(), cnt.data())) die("%s", bc_last_error());
-    for (uint64_t i = 0; i < n_rows; ++i) {
-      const std::string key = sample_group ? r.samples[sidx[i]].first : std::string("barcode");
-      std::string tuple;
-      for (uint32_t b = 0; b < r.barcode_num; ++b) tuple += (b ? "," : "") + std::string(bc_plan_counted_seq(r.plan, b, bidx[i * nb + b]));
-      if (!r.results.count(key) && std::find(r.sample_keys.begin(), r.sample_keys.end(), key) == r.sample_keys.end())
-        r.sample_keys.push_back(key);  // random barcode + sample file without a sample group: "barcode" appears (info.rs:792-801)
-      r.results[key].emplace_back(tuple, cnt[i]);
-      if (r.args.merge_output) r.results_map[key][tuple] = cnt[i];
-    }
+  for (uint64_t i = 0; i < n_rows; ++i) {
+    char sample[64], tuple[2048];
+    uint64_t cnt = 0;
+    if (bc_engine_row_text(r.engine, i, sample, sizeof sample, tuple, sizeof tuple, &cnt)) die("%s", bc_last_error());
+    const std::string key = sample;
+    // keys that only exist once a read lands on them: raw sample barcodes (info.rs:742-757) and the
+    // "barcode" entry of a random-barcode run with a sample file but no sample group (info.rs:792-801)
+    if (!r.results.count(key) && std::find(r.sample_keys.begin(), r.sample_keys.end(), key) == r.sample_keys.end())
+      r.sample_keys.push_back(key);
+    r.results[key].emplace_back(tuple, cnt);
+    if (r.args.merge_output) r.results_map[key][tuple] = cnt;
   }
   r.counted_map.resize(r.counted.size());
   for (size_t b = 0; b < r.counted.size(); ++b)

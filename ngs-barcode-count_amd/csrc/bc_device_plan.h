@@ -36,7 +36,8 @@ struct DevGroup {
   uint32_t max_err;    // MaxSeqErrors budget of this group
   uint32_t hmask;      // hash slots - 1
   uint32_t has_odd;    // set holds refs with 'N' or of a different length (no single-N shortcut)
-  uint64_t table_stride;  // multiplier of this group's index in the dense counter index
+  uint64_t table_stride;  // multiplier of this group's value (reference index, or base-5 code of a raw
+                          // capture) in the mixed-radix tuple key = dense counter index
   // kSetDirect: one u32 per N-free capture q1 | q2 << len:
   //   bits 0-15 fix_error's verdict (reference index, kFail16 = None)
   //   bits 16-23 distance of the nearest reference (capped at 255), bit 24 set when only one reference is that near
@@ -71,7 +72,9 @@ struct DevPlan {
   uint32_t has_fmtn;
   // random barcode (PCR-duplicate collapse, info.rs:770-802): the capture is kept raw; its base-5
   // code (A,C,T,G,N -> 0,1,2,3,4) and the dense tuple index form one 64-bit key of a device hash set
-  uint32_t has_random, rnd_off, rnd_len, rnd_pad;
+  uint32_t has_random, rnd_off, rnd_len;
+  uint32_t sparse;      // some group has no known set: its capture's base-5 code is part of the key and
+                        // the (then astronomically large) key space is held in a hash map, not a table
   uint64_t rspace;      // 5^rnd_len: key = dense_idx * rspace + code
   uint32_t ablate;      // perf-debug only (env BC_ABLATE): bit mask of phases to skip; results are then wrong
   // Per position class a program that walks the class's format positions in ascending order,

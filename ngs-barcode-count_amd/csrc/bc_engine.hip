@@ -205,6 +205,16 @@ __device__ __forceinline__ bool set_insert(unsigned long long* __restrict__ slot
   }
 }
 
+// slot of the key in a hash map, inserting it when absent
+__device__ __forceinline__ uint64_t map_slot(unsigned long long* __restrict__ slots, uint64_t mask, uint64_t key) {
+  uint64_t h = hash64(key) & mask;
+  for (;;) {
+    const unsigned long long old = atomicCAS(&slots[h], kEmptyKey, (unsigned long long)key);
+    if (old == kEmptyKey || old == key) return h;
+    h = (h + 1) & mask;
+  }
+}
+
 struct DeviceOps {
   uint8_t* tile;          // this wave's LDS region
   const uint8_t* qsrc;    // this wave's quality lines in global memory
@@ -249,7 +259,8 @@ __global__ __launch_bounds__(kTPB, ((NW <= 4 && NWW <= 2) ? BC_MIN_WAVES : 1)) v
                                                            const uint16_t* __restrict__ lens, uint32_t stride,
                                                            uint32_t read_len, uint32_t nd, uint64_t n_reads,
                                                            uint32_t region, uint32_t* __restrict__ table,
-                                                           unsigned long long* __restrict__ slots, uint64_t smask,
+                                                           unsigned long long* __restrict__ slots, uint32_t* __restrict__ vals,
+                                                           uint64_t smask,
                                                            unsigned long long* __restrict__ counters,
                                                            uint8_t* __restrict__ trace_outcome,
                                                            uint64_t* __restrict__ trace_idx) {
@@ -298,8 +309,12 @@ __global__ __launch_bounds__(kTPB, ((NW <= 4 && NWW <= 2) ? BC_MIN_WAVES : 1)) v
       if (active && outcome == kMatched && !set_insert(slots, smask, r.dense_idx * pl.rspace + r.rcode))
         outcome = kDuplicate;
     } else if (active && outcome == kMatched && !pl.discard_counts && !(pl.ablate & 0x4u)) {
-      // Results::add_count (info.rs:761-767): one no-return atomic into the dense counter table
-      atomicAdd(&table[r.dense_idx], 1u);
+      // Results::add_count (info.rs:761-767): one no-return atomic into the dense counter table, or,
+      // when captures are kept raw, into the hash map slot of the tuple key
+      if (pl.sparse)
+        atomicAdd(&vals[map_slot(slots, smask, r.dense_idx)], 1u);
+      else
+        atomicAdd(&table[r.dense_idx], 1u);
     }
     // outcome counters (SequenceErrors, info.rs:16-139)
 #pragma unroll
@@ -365,6 +380,43 @@ __global__ void set_insert_kernel(const unsigned long long* __restrict__ src, ui
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
     if (__lane_id() == 0 && c) atomicAdd(n_new, (unsigned long long)c);
+  }
+}
+
+// moves (key, value) pairs into a larger map
+__global__ void map_rehash_kernel(const unsigned long long* __restrict__ src, const uint32_t* __restrict__ src_vals,
+                                  uint64_t n, unsigned long long* dst, uint32_t* dst_vals, uint64_t dmask) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    const unsigned long long k = src[i];
+    if (k != kEmptyKey) atomicAdd(&dst_vals[map_slot(dst, dmask, k)], src_vals[i]);
+  }
+}
+
+// raw captures + random barcode: count of a tuple = number of its distinct (tuple, random) keys
+__global__ void set_to_map_kernel(const unsigned long long* __restrict__ slots, uint64_t n, uint64_t rspace,
+                                  unsigned long long* dst, uint32_t* dst_vals, uint64_t dmask) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    const unsigned long long k = slots[i];
+    if (k != kEmptyKey) atomicAdd(&dst_vals[map_slot(dst, dmask, k / rspace)], 1u);
+  }
+}
+
+__global__ void map_export_kernel(const unsigned long long* __restrict__ slots, const uint32_t* __restrict__ vals,
+                                  uint64_t n, unsigned long long* cursor, uint64_t* __restrict__ out_key,
+                                  uint32_t* __restrict__ out_cnt) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    const unsigned long long k = slots[i];
+    if (k != kEmptyKey) {
+      const unsigned long long p = atomicAdd(cursor, 1ull);
+      out_key[p] = k;
+      out_cnt[p] = vals[i];
+    }
   }
 }
 
@@ -466,6 +518,7 @@ struct bc_engine {
   unsigned long long* d_counters = nullptr;
   uint32_t barcode_num = 0;
   uint32_t n_sets[kMaxGroups] = {0};
+  std::vector<std::vector<std::string>> set_seqs;  // per group: the known sequences in index order
   bool has_sample_group = false;
   uint8_t* trace_outcome = nullptr;
   uint64_t* trace_idx = nullptr;
@@ -487,6 +540,7 @@ struct bc_engine {
   uint32_t n_cus = 0;
   // random-barcode mode: the hash set of (tuple, random barcode) keys
   unsigned long long* d_slots = nullptr;
+  uint32_t* d_vals = nullptr;  // sparse plans without a random barcode: the count of each key
   uint64_t n_slots = 0;
   uint64_t key_bound = 0;  // upper bound on the keys held: reads submitted / keys imported so far
 };
@@ -517,6 +571,7 @@ static void engine_free(bc_engine* e) {
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->own_table && e->d_table) (void)hipFree(e->d_table);
   if (e->d_slots) (void)hipFree(e->d_slots);
+  if (e->d_vals) (void)hipFree(e->d_vals);
   if (e->d_counters) (void)hipFree(e->d_counters);
   if (e->d_plan) (void)hipFree(e->d_plan);
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
@@ -547,6 +602,11 @@ static int engine_init(bc_engine* e, const bc_plan* p, int device_id, void* hip_
   e->n_cus = (uint32_t)prop.multiProcessorCount;
   e->barcode_num = p->barcode_num;
   e->has_sample_group = p->sample_barcode;
+  {
+    // groups are ordered sample first, then counted barcodes (bc_plan::lower)
+    if (p->sample_barcode) e->set_seqs.push_back(p->samples.seqs);
+    for (uint32_t b = 0; b < p->barcode_num; ++b) e->set_seqs.push_back(p->counted[b].seqs);
+  }
 
   DevPlan& P = e->h.plan;
   if (const char* ab = getenv("BC_ABLATE")) P.ablate = (uint32_t)strtoul(ab, nullptr, 0);
@@ -585,8 +645,13 @@ static int engine_init(bc_engine* e, const bc_plan* p, int device_id, void* hip_
                        const_cast<uint32_t*>(G.dtable));
     HIP_TRY(hipGetLastError());
   }
-  e->table_entries = e->h.table_entries;
-  if (table_mem) {
+  e->table_entries = P.sparse ? 0 : e->h.table_entries;
+  if (P.sparse) {
+    if (table_mem) {
+      set_error("bc_engine_create: the plan keeps raw captures (no dense table); pass table_mem = NULL");
+      return BC_ERR_INVALID;
+    }
+  } else if (table_mem) {
     e->d_table = (uint32_t*)table_mem;
   } else {
     HIP_TRY(hipMalloc((void**)&e->d_table, e->table_entries * 4));
@@ -627,7 +692,7 @@ static int launch_match(bc_engine* e, const void* d_seq, const void* d_qual, con
   }
   hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(kTPB), lds, e->stream, e->d_plan, (const uint8_t*)d_seq,
                      (const uint8_t*)d_qual, (const uint16_t*)d_lens, stride, read_len, nd, n_reads, tile_alloc,
-                     e->d_table, e->d_slots, e->n_slots ? e->n_slots - 1 : 0, e->d_counters, e->trace_outcome ? e->trace_outcome + trace_off : nullptr,
+                     e->d_table, e->d_slots, e->d_vals, e->n_slots ? e->n_slots - 1 : 0, e->d_counters, e->trace_outcome ? e->trace_outcome + trace_off : nullptr,
                      e->trace_idx ? e->trace_idx + trace_off : nullptr);
   HIP_TRY(hipGetLastError());
   if (e->timing) {
@@ -642,22 +707,35 @@ static uint32_t grid_for(uint64_t n) { return (uint32_t)std::min<uint64_t>((n + 
 // Random-barcode mode: keeps the hash set at most half full for `more` further keys.  Growing
 // allocates a set of twice the size (or more) and re-inserts the old keys on the device.
 static int set_reserve(bc_engine* e, uint64_t more) {
-  if (!e->h.plan.has_random) return BC_OK;
+  const DevPlan& P = e->h.plan;
+  if (!P.has_random && !P.sparse) return BC_OK;
+  const bool with_vals = P.sparse && !P.has_random;
   e->key_bound += more;
   uint64_t want = 1ull << 20;
   while (want < 2 * e->key_bound) want <<= 1;
   if (want <= e->n_slots) return BC_OK;
   unsigned long long* fresh = nullptr;
+  uint32_t* fresh_vals = nullptr;
   HIP_TRY(hipMalloc((void**)&fresh, want * 8));
   hipLaunchKernelGGL(set_fill_kernel, dim3(grid_for(want)), dim3(256), 0, e->stream, fresh, want);
+  if (with_vals) {
+    HIP_TRY(hipMalloc((void**)&fresh_vals, want * 4));
+    HIP_TRY(hipMemsetAsync(fresh_vals, 0, want * 4, e->stream));
+  }
   if (e->d_slots) {
-    hipLaunchKernelGGL(set_insert_kernel, dim3(grid_for(e->n_slots)), dim3(256), 0, e->stream, e->d_slots, e->n_slots,
-                       fresh, want - 1, (unsigned long long*)nullptr);
+    if (with_vals)
+      hipLaunchKernelGGL(map_rehash_kernel, dim3(grid_for(e->n_slots)), dim3(256), 0, e->stream, e->d_slots, e->d_vals,
+                         e->n_slots, fresh, fresh_vals, want - 1);
+    else
+      hipLaunchKernelGGL(set_insert_kernel, dim3(grid_for(e->n_slots)), dim3(256), 0, e->stream, e->d_slots, e->n_slots,
+                         fresh, want - 1, (unsigned long long*)nullptr);
     HIP_TRY(hipStreamSynchronize(e->stream));
     (void)hipFree(e->d_slots);
+    if (e->d_vals) (void)hipFree(e->d_vals);
   }
   HIP_TRY(hipGetLastError());
   e->d_slots = fresh;
+  e->d_vals = fresh_vals;
   e->n_slots = want;
   return BC_OK;
 }
@@ -806,11 +884,12 @@ int bc_engine_sync(bc_engine* e) {
 
 int bc_engine_reset(bc_engine* e) {
   HIP_TRY(hipSetDevice(e->device));
-  HIP_TRY(hipMemsetAsync(e->d_table, 0, e->table_entries * 4, e->stream));
+  if (e->d_table) HIP_TRY(hipMemsetAsync(e->d_table, 0, e->table_entries * 4, e->stream));
   HIP_TRY(hipMemsetAsync(e->d_counters, 0, BC_NCOUNTERS * 8, e->stream));
   if (e->d_slots) {
     hipLaunchKernelGGL(set_fill_kernel, dim3(grid_for(e->n_slots)), dim3(256), 0, e->stream, e->d_slots, e->n_slots);
     HIP_TRY(hipGetLastError());
+    if (e->d_vals) HIP_TRY(hipMemsetAsync(e->d_vals, 0, e->n_slots * 4, e->stream));
   }
   e->key_bound = 0;
   return BC_OK;
@@ -833,9 +912,63 @@ int bc_engine_trace(bc_engine* e, void* d_outcome_u8, void* d_index_u64) {
   return BC_OK;
 }
 
+// rows of a sparse plan: (tuple key, count) pairs straight out of the hash map
+static int finish_sparse(bc_engine* e, uint64_t* n_rows) {
+  const DevPlan& P = e->h.plan;
+  e->row_idx.clear();
+  e->row_cnt.clear();
+  if (n_rows) *n_rows = 0;
+  if (!e->d_slots) return BC_OK;
+  unsigned long long* keys = e->d_slots;
+  uint32_t* vals = e->d_vals;
+  uint64_t n_slots = e->n_slots;
+  unsigned long long* agg_keys = nullptr;
+  uint32_t* agg_vals = nullptr;
+  if (P.has_random) {
+    // count of a tuple = number of its distinct random barcodes (output.rs:265-270)
+    HIP_TRY(hipMalloc((void**)&agg_keys, n_slots * 8));
+    HIP_TRY(hipMalloc((void**)&agg_vals, n_slots * 4));
+    hipLaunchKernelGGL(set_fill_kernel, dim3(grid_for(n_slots)), dim3(256), 0, e->stream, agg_keys, n_slots);
+    HIP_TRY(hipMemsetAsync(agg_vals, 0, n_slots * 4, e->stream));
+    hipLaunchKernelGGL(set_to_map_kernel, dim3(grid_for(n_slots)), dim3(256), 0, e->stream, e->d_slots, n_slots, P.rspace,
+                       agg_keys, agg_vals, n_slots - 1);
+    HIP_TRY(hipGetLastError());
+    keys = agg_keys;
+    vals = agg_vals;
+  }
+  unsigned long long* d_n = nullptr;
+  uint64_t* d_key = nullptr;
+  uint32_t* d_cnt = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_n, 8));
+  HIP_TRY(hipMemsetAsync(d_n, 0, 8, e->stream));
+  // upper bound on the rows: the keys held
+  const uint64_t cap = std::min<uint64_t>(n_slots, e->key_bound ? e->key_bound : 1);
+  HIP_TRY(hipMalloc((void**)&d_key, cap * 8));
+  HIP_TRY(hipMalloc((void**)&d_cnt, cap * 4));
+  hipLaunchKernelGGL(map_export_kernel, dim3(grid_for(n_slots)), dim3(256), 0, e->stream, keys, vals, n_slots, d_n, d_key,
+                     d_cnt);
+  unsigned long long n = 0;
+  HIP_TRY(hipMemcpyAsync(&n, d_n, 8, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->row_idx.resize(n);
+  e->row_cnt.resize(n);
+  if (n) {
+    HIP_TRY(hipMemcpy(e->row_idx.data(), d_key, n * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(e->row_cnt.data(), d_cnt, n * 4, hipMemcpyDeviceToHost));
+  }
+  (void)hipFree(d_n);
+  (void)hipFree(d_key);
+  (void)hipFree(d_cnt);
+  if (agg_keys) (void)hipFree(agg_keys);
+  if (agg_vals) (void)hipFree(agg_vals);
+  if (n_rows) *n_rows = n;
+  return BC_OK;
+}
+
 int bc_engine_finish(bc_engine* e, uint64_t* n_rows) {
   int rc = bc_engine_sync(e);
   if (rc) return rc;
+  if (e->h.plan.sparse) return finish_sparse(e, n_rows);
   if (e->h.plan.has_random) {
     // the count of a tuple is the number of distinct random barcodes seen with it (output.rs:265-270)
     HIP_TRY(hipMemsetAsync(e->d_table, 0, e->table_entries * 4, e->stream));
@@ -880,6 +1013,10 @@ int bc_engine_rows(bc_engine* e, uint64_t first, uint64_t n, uint32_t* sample_id
     return BC_ERR_STATE;
   }
   const DevPlan& P = e->h.plan;
+  if (P.sparse) {
+    set_error("bc_engine_rows: the plan keeps raw captures, which have no index; use bc_engine_row_text");
+    return BC_ERR_STATE;
+  }
   const uint32_t nb = e->barcode_num ? e->barcode_num : 1;
   const uint32_t g0 = e->has_sample_group ? 1u : 0u;  // groups[0] is the sample group when present
   for (uint64_t r = 0; r < n; ++r) {
@@ -957,6 +1094,51 @@ int bc_engine_clear_keys(bc_engine* e) {
     HIP_TRY(hipGetLastError());
   }
   e->key_bound = 0;
+  return BC_OK;
+}
+
+int bc_engine_row_text(bc_engine* e, uint64_t row, char* sample, size_t sample_cap, char* tuple, size_t tuple_cap,
+                       uint64_t* count) {
+  if (row >= e->row_idx.size()) {
+    set_error("bc_engine_row_text: row outside the compacted rows (call bc_engine_finish first)");
+    return BC_ERR_STATE;
+  }
+  const DevPlan& P = e->h.plan;
+  uint64_t key = e->row_idx[row];
+  std::string s_out = "barcode", t_out;  // parse.rs:473: the sample key without a sample group
+  std::vector<std::string> parts(P.n_groups);
+  for (int g = (int)P.n_groups - 1; g >= 0; --g) {
+    const DevGroup& G = P.groups[g];
+    std::string v;
+    if (G.mode == kSetNone) {
+      uint64_t radix = 1;
+      for (uint32_t k = 0; k < G.len; ++k) radix *= 5;
+      uint64_t code = key % radix;
+      key /= radix;
+      for (uint32_t k = 0; k < G.len; ++k) {
+        v.push_back("ACTGN"[code % 5]);
+        code /= 5;
+      }
+    } else {
+      const uint32_t idx = (uint32_t)(key % G.n_refs);
+      key /= G.n_refs;
+      v = e->set_seqs[g][idx];
+    }
+    parts[g] = v;
+  }
+  for (uint32_t g = 0; g < P.n_groups; ++g) {
+    if (P.groups[g].type == kGroupSample)
+      s_out = parts[g];
+    else
+      t_out += (t_out.empty() ? "" : ",") + parts[g];
+  }
+  if (s_out.size() + 1 > sample_cap || t_out.size() + 1 > tuple_cap) {
+    set_error("bc_engine_row_text: buffer too small");
+    return BC_ERR_INVALID;
+  }
+  memcpy(sample, s_out.c_str(), s_out.size() + 1);
+  memcpy(tuple, t_out.c_str(), t_out.size() + 1);
+  if (count) *count = e->row_cnt[row];
   return BC_OK;
 }
 

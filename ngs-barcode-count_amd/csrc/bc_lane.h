@@ -168,6 +168,16 @@ BC_HD void extract_planes(const Planes<NW>& P, uint32_t off, uint32_t len, uint3
   }
 }
 
+// base-5 code of a capture kept raw: A,C,T,G,N -> 0,1,2,3,4, base 0 least significant
+BC_HD uint64_t base5_code(uint32_t q1, uint32_t q2, uint32_t qn, uint32_t len) {
+  uint64_t code = 0;
+  for (uint32_t i = len; i-- > 0;) {
+    const uint32_t d = ((qn >> i) & 1u) ? 4u : (((q1 >> i) & 1u) | (((q2 >> i) & 1u) << 1));
+    code = code * 5u + d;
+  }
+  return code;
+}
+
 // bit `pos` of a vector, pos per lane
 template <int NW>
 BC_HD uint32_t test_bit(const uint32_t (&v)[NW], uint32_t pos) {
@@ -661,9 +671,9 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
       q1[u] = q2[u] = qn[u] = qx[u] = 0;
       if (g0 + u < ng) {  // wave-uniform
         const DevGroup& G = pl.groups[g0 + u];
+        extract_planes<NW>(P, G.off, G.len, q1[u], q2[u], qn[u]);
+        if (anyx) qx[u] = extract_uniform<NW>(P.px, G.off, G.len);
         if (G.mode != kSetNone) {
-          extract_planes<NW>(P, G.off, G.len, q1[u], q2[u], qn[u]);
-          if (anyx) qx[u] = extract_uniform<NW>(P.px, G.off, G.len);
           const bool clean = (qn[u] | qx[u]) == 0u;
           if (pre_ok) {
             if (G.mode == kSetDirect) {
@@ -714,6 +724,10 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
             else
               didx += (uint64_t)r[u] * G.table_stride;
           }
+        } else if (pre_ok && outcome == kMatched) {
+          // no known set: the capture is taken as it is (parse.rs:453-454, 487)
+          if (qx[u]) unsupported = true;  // a byte outside ACGTN has no code
+          didx += base5_code(q1[u], q2[u], qn[u], G.len) * G.table_stride;
         }
       }
     }
@@ -723,13 +737,8 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
     uint32_t r1, r2, rn;
     extract_planes<NW>(P, pl.rnd_off, pl.rnd_len, r1, r2, rn);
     const uint32_t rx = anyx ? extract_uniform<NW>(P.px, pl.rnd_off, pl.rnd_len) : 0u;
-    if (rx) unsupported = true;  // a byte outside ACGTN has no code
-    uint64_t code = 0;
-    for (uint32_t i = pl.rnd_len; i-- > 0;) {
-      const uint32_t d = ((rn >> i) & 1u) ? 4u : (((r1 >> i) & 1u) | (((r2 >> i) & 1u) << 1));
-      code = code * 5u + d;
-    }
-    res.rcode = code;
+    if (rx && active && outcome == kMatched) unsupported = true;  // a byte outside ACGTN has no code
+    res.rcode = base5_code(r1, r2, rn, pl.rnd_len);
   }
   if (unsupported) outcome = kUnsupported;
   res.outcome = outcome;

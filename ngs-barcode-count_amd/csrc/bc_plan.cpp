@@ -147,14 +147,6 @@ bool bc_plan::lower(HostDevPlan& out) const {
     set_error("unsupported scheme: format length must be 1.." + std::to_string(kMaxNW * 32));
     return false;
   }
-  if (sample_barcode && samples.size() == 0) {
-    set_error("unsupported plan: sample barcode in the scheme without a sample barcode file (raw-key mode)");
-    return false;
-  }
-  if (barcode_num > 0 && !counted_loaded) {
-    set_error("unsupported plan: counted barcodes without a counted barcode file (raw-key mode)");
-    return false;
-  }
   if (max_constant > 31) {
     set_error("unsupported plan: --max-errors-constant above 31");
     return false;
@@ -282,9 +274,25 @@ bool bc_plan::lower(HostDevPlan& out) const {
     G.n_refs = (uint32_t)pd.set->size();
     G.max_err = pd.max_err;
     G.table_stride = (uint64_t)entries;
+    if (G.n_refs == 0) {
+      // no known set (sample_seqs.is_empty() parse.rs:453 / counted_barcode_seqs.is_empty() parse.rs:487):
+      // the capture itself is the key; its base-5 code takes the place of a reference index
+      if (G.len > 27) {
+        set_error("unsupported plan: barcodes without a conversion file must be at most 27 bases");
+        return false;
+      }
+      G.mode = kSetNone;
+      P.sparse = 1;
+      for (uint32_t k = 0; k < G.len; ++k) entries *= 5;
+      if (entries >= ((unsigned __int128)1 << 63)) {
+        set_error("unsupported plan: the barcodes without conversion files do not fit a 64-bit key");
+        return false;
+      }
+      continue;
+    }
     entries *= G.n_refs;
-    if (entries > ((unsigned __int128)1 << 40)) {
-      set_error("unsupported plan: dense counter table above 2^40 entries");
+    if (entries >= ((unsigned __int128)1 << 63)) {
+      set_error("unsupported plan: the (sample, barcode tuple) space does not fit a 64-bit key");
       return false;
     }
     HostSet& H = out.sets[i];
@@ -362,7 +370,11 @@ bool bc_plan::lower(HostDevPlan& out) const {
       }
     }
   }
-  out.table_entries = (uint64_t)entries;
+  if (!P.sparse && entries > ((unsigned __int128)1 << 40)) {
+    set_error("unsupported plan: dense counter table above 2^40 entries");
+    return false;
+  }
+  out.table_entries = (uint64_t)entries;  // dense plans: table size; sparse plans: size of the tuple-key space
   if (random_barcode) {
     for (const auto& g : groups) {
       if (g.type != kGroupRandom) continue;
@@ -617,7 +629,13 @@ uint32_t bc_plan_quality_threshold(const bc_plan* p, uint32_t run_len) { return 
 uint64_t bc_plan_table_entries(const bc_plan* p) {
   bc::HostDevPlan h;
   if (!p->lower(h)) return 0;
-  return h.table_entries;
+  return h.plan.sparse ? 0 : h.table_entries;
+}
+
+int bc_plan_mode(const bc_plan* p) {
+  bc::HostDevPlan h;
+  if (!p->lower(h)) return 0;
+  return h.plan.sparse ? 2 : 1;
 }
 
 }  // extern "C"

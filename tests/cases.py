@@ -108,6 +108,28 @@ def build_case(name, seed=0, n=600):
         c["counted"] = [["CAGAGA", "TGATTG"], ["ATGAAA", "GCGCCA"], ["GATAGC", "TTAGCT"]]
         c["reads"] = readgen.gen_reads(rng, c["scheme"], n, 70, None, c["counted"], p_sub=0.01, p_n=0.004,
                                        dup_frac=0.3)
+    elif name == "raw_counted":
+        # Barcode-seq style: no counted-barcode file, captures are the keys (README.md:149-152)
+        c["scheme"] = NOSAMPLE_SCHEME
+        c["samples"] = None
+        c["counted"] = None
+        c["kwargs"] = dict(min_quality=25.0)
+        pool = [readgen.make_set(rng, 12, 9, 2), readgen.make_set(rng, 5, 4, 2)]
+        c["reads"] = readgen.gen_reads(rng, NOSAMPLE_SCHEME, n, 50, None, pool, p_sub=0.02, p_n=0.01)
+    elif name == "raw_sample":
+        # sample barcode in the scheme but no sample file: sample captures become keys (info.rs:742-757)
+        c["scheme"] = DEL_SCHEME
+        c["samples"] = None
+        c["counted"] = [readgen.make_set(rng, 20, 8, 2) for _ in range(3)]
+        pool = readgen.make_set(rng, 6, 8, 3)
+        c["reads"] = readgen.gen_reads(rng, DEL_SCHEME, n, 100, pool, c["counted"], p_sub=0.02, p_n=0.004)
+    elif name == "raw_all_random":
+        c["scheme"] = "[5]ACGTTGCA{6}GGATC(7)TTGACA"
+        c["samples"] = None
+        c["counted"] = None
+        pool = [readgen.make_set(rng, 6, 6, 2)]
+        c["reads"] = readgen.gen_reads(rng, c["scheme"], n, 60, readgen.make_set(rng, 3, 5, 2), pool, p_sub=0.01,
+                                       p_n=0.01, dup_frac=0.4)
     elif name == "long_gaps":
         c["scheme"] = GAP_SCHEME
         s = readgen.make_set(rng, 3, 32, 6)
@@ -122,9 +144,10 @@ def build_case(name, seed=0, n=600):
 
 ALL_CASES = ["del_exact", "del_mismatch_quality", "del_dense_ties", "del_random", "example_files",
              "example_files_samples", "crispr", "fmtn", "nosample_with_sample_file", "nosample",
-             "refs_with_n_and_ragged", "other_chars", "long_gaps", "example_files_random_nosample"]
+             "refs_with_n_and_ragged", "other_chars", "long_gaps", "example_files_random_nosample", "raw_counted",
+             "raw_sample", "raw_all_random"]
 
-RANDOM_CASES = ["del_random", "example_files", "example_files_samples", "example_files_random_nosample"]
+RANDOM_CASES = ["del_random", "example_files", "example_files_samples", "example_files_random_nosample",
+                "raw_all_random"]
 NO_RANDOM_CASES = [c for c in ALL_CASES if c not in RANDOM_CASES]
-# "example_files" has a sample group but no sample file: raw-key mode, which the engine refuses for now
-RANDOM_ENGINE_CASES = [c for c in RANDOM_CASES if c != "example_files"]
+RANDOM_ENGINE_CASES = list(RANDOM_CASES)

@@ -12,20 +12,43 @@ def oracle_for(case):
     return oracle_lib.Oracle(case["scheme"], samples=case.get("samples"), counted=case.get("counted"), **kw)
 
 
+def _base5_text(code, n):
+    out = []
+    for _ in range(n):
+        out.append("ACTGN"[code % 5])
+        code //= 5
+    return "".join(out)
+
+
 def decode_rows(plan, idx_counts, discard):
-    """{dense index: count} -> sorted [(sample, tuple, count)] with the plan's sequences as keys"""
+    """{tuple key: count} -> sorted [(sample, tuple, count)] with sequences as keys.  The key is the
+    mixed-radix number over (sample, barcode 1..n): a reference index where a known set exists, the
+    base-5 code of the raw capture where none does"""
     if discard:
         return []
-    samples = [s for s, _ in plan.samples()] if plan.sample_barcode else ["barcode"]
-    sets = [[s for s, _ in plan.counted(i)] for i in range(plan.barcode_num)]
+    groups = []  # (is_sample, known sequences or None, capture length)
+    if plan.sample_barcode:
+        s = [x for x, _ in plan.samples()]
+        groups.append((True, s or None, plan.sample_length_option))
+    for i, bl in enumerate(plan.barcode_lengths):
+        st = [x for x, _ in plan.counted(i)]
+        groups.append((False, st or None, bl))
     out = []
     for di, cnt in idx_counts.items():
         di = int(di)
-        parts = []
-        for st in reversed(sets):
-            parts.append(st[di % len(st)])
-            di //= len(st)
-        out.append((samples[di], ",".join(reversed(parts)), int(cnt)))
+        sample, parts = "barcode", []
+        for is_sample, known, ln in reversed(groups):
+            if known:
+                v = known[di % len(known)]
+                di //= len(known)
+            else:
+                v = _base5_text(di % (5 ** ln), ln)
+                di //= 5 ** ln
+            if is_sample:
+                sample = v
+            else:
+                parts.append(v)
+        out.append((sample, ",".join(reversed(parts)), int(cnt)))
     return sorted(out)
 
 

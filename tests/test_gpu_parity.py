@@ -187,8 +187,10 @@ def test_submit_host_equals_submit_device():
 
 def test_errors_are_loud():
     pkg = _pkg()
-    with pytest.raises(pkg.BarcodeCountError):  # raw-key mode is not built yet: refuse, never guess
-        pkg.Engine(pkg.Plan("[8]ACGT{8}"), device=0)
+    with pytest.raises(pkg.BarcodeCountError):  # lower-case scheme letters: refused, never guessed
+        pkg.Engine(pkg.Plan("[8]acgt{8}"), device=0)
+    with pytest.raises(pkg.BarcodeCountError):  # raw barcodes that do not fit a 64-bit key
+        pkg.Engine(pkg.Plan("[20]ACGT{20}TT{20}"), device=0)
     p = make_plan(dict(scheme="ACGTACGT{8}TTGG", counted=[["ACGTACGT"]], kwargs=dict(min_quality=10.0)))
     e = pkg.Engine(p, device=0)
     import torch
