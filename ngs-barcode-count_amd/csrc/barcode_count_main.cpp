@@ -215,7 +215,12 @@ struct Run {
   std::vector<std::vector<std::pair<std::string, std::string>>> counted;  // per barcode position
   // Results (info.rs:661-665) rebuilt from the engine's rows: sample key -> (tuple of sequences -> count)
   std::vector<std::string> sample_keys;
-  std::unordered_map<std::string, std::vector<std::pair<std::string, uint64_t>>> results;
+  struct Row {
+    std::string code;     // "b1,b2,.." as sequences (the key Results holds)
+    std::string written;  // the same converted to IDs when a counted-barcode file was given (output.rs:282-287)
+    uint64_t count;
+  };
+  std::unordered_map<std::string, std::vector<Row>> results;
   std::unordered_map<std::string, std::unordered_map<std::string, uint64_t>> results_map;  // for the merged file
   std::vector<std::unordered_map<std::string, std::string>> counted_map;                  // sequence -> ID
   // WriteFiles state (output.rs:33-46)
@@ -350,24 +355,22 @@ enum Enriched { kSingle, kDouble, kFull };
 
 // add_counts_string (output.rs:199-361)
 uint64_t add_counts_string(Run& r, const std::string& sample, const std::vector<std::string>& samples, Enriched type) {
-  std::vector<std::pair<std::string, uint64_t>> rows;
+  std::vector<Run::Row> enriched_rows;
   const std::unordered_map<std::string, std::map<std::string, uint64_t>> holder =
       type == kSingle ? r.single_hash : (type == kDouble ? r.double_hash : decltype(r.single_hash)());
-  if (type == kFull) {
-    rows = r.results[sample];
-  } else {
-    for (const auto& kv : holder.at(sample)) rows.emplace_back(kv.first, kv.second);
-  }
+  if (type != kFull)
+    for (const auto& kv : holder.at(sample)) enriched_rows.push_back({kv.first, kv.first, kv.second});
+  const std::vector<Run::Row>& rows = type == kFull ? r.results[sample] : enriched_rows;
   uint64_t barcode_num = 0;
   for (const auto& row : rows) {
-    const std::string& code = row.first;
-    const uint64_t count = row.second;
+    const std::string& code = row.code;
+    const uint64_t count = row.count;
     ++barcode_num;
     if (barcode_num % 50000 == 0) {
       printf("Barcodes counted: %s\r", commas(barcode_num).c_str());
       fflush(stdout);
     }
-    const std::string written = (type == kFull && !r.counted.empty()) ? convert_code(r, code) : code;
+    const std::string& written = row.written;
     if (r.args.merge_output) {
       if (r.compounds_written.insert(code).second) {
         r.merged_count++;
@@ -600,21 +603,51 @@ int main(int argc, char** argv) {
   if (r.samples.empty() && !sample_group) r.sample_keys.push_back("barcode");
   uint64_t n_rows = 0;
   if (bc_engine_finish(r.engine, &n_rows)) die("%s", bc_last_error());
-  for (uint64_t i = 0; i < n_rows; ++i) {
-    char sample[64], tuple[2048];
-    uint64_t cnt = 0;
-    if (bc_engine_row_text(r.engine, i, sample, sizeof sample, tuple, sizeof tuple, &cnt)) die("%s", bc_last_error());
-    const std::string key = sample;
-    // keys that only exist once a read lands on them: raw sample barcodes (info.rs:742-757) and the
-    // "barcode" entry of a random-barcode run with a sample file but no sample group (info.rs:792-801)
-    if (!r.results.count(key) && std::find(r.sample_keys.begin(), r.sample_keys.end(), key) == r.sample_keys.end())
-      r.sample_keys.push_back(key);
-    r.results[key].emplace_back(tuple, cnt);
-    if (r.args.merge_output) r.results_map[key][tuple] = cnt;
-  }
   r.counted_map.resize(r.counted.size());
   for (size_t b = 0; b < r.counted.size(); ++b)
     for (const auto& kv : r.counted[b]) r.counted_map[b][kv.first] = kv.second;
+  auto add_row = [&](const std::string& key, const std::string& code, const std::string& written, uint64_t cnt) {
+    // keys that only exist once a read lands on them: raw sample barcodes (info.rs:742-757) and the
+    // "barcode" entry of a random-barcode run with a sample file but no sample group (info.rs:792-801)
+    auto it = r.results.find(key);
+    if (it == r.results.end()) {
+      if (std::find(r.sample_keys.begin(), r.sample_keys.end(), key) == r.sample_keys.end()) r.sample_keys.push_back(key);
+      it = r.results.emplace(key, std::vector<Run::Row>()).first;
+    }
+    it->second.push_back({code, written, cnt});
+    if (r.args.merge_output) r.results_map[key][code] = cnt;
+  };
+  if (bc_plan_mode(r.plan) == 1) {
+    // dense plan: rows come as indices into the known sets; the sequence / ID strings are looked up
+    const uint32_t nb = r.barcode_num ? r.barcode_num : 1;
+    const uint64_t block = 1u << 20;
+    std::vector<uint32_t> sidx(block), bidx(block * nb);
+    std::vector<uint64_t> cnt(block);
+    for (uint64_t first = 0; first < n_rows; first += block) {
+      const uint64_t n = std::min(block, n_rows - first);
+      if (bc_engine_rows(r.engine, first, n, sidx.data(), bidx.data(), cnt.data())) die("%s", bc_last_error());
+      for (uint64_t i = 0; i < n; ++i) {
+        std::string code, written;
+        for (uint32_t b = 0; b < r.barcode_num; ++b) {
+          const auto& kv = r.counted[b][bidx[i * nb + b]];
+          if (b) {
+            code.push_back(',');
+            written.push_back(',');
+          }
+          code += kv.first;
+          written += kv.second;
+        }
+        add_row(sample_group ? r.samples[sidx[i]].first : std::string("barcode"), code, written, cnt[i]);
+      }
+    }
+  } else {
+    for (uint64_t i = 0; i < n_rows; ++i) {
+      char sample[64], tuple[2048];
+      uint64_t cnt = 0;
+      if (bc_engine_row_text(r.engine, i, sample, sizeof sample, tuple, sizeof tuple, &cnt)) die("%s", bc_last_error());
+      add_row(sample, tuple, r.counted.empty() ? std::string(tuple) : convert_code(r, tuple), cnt);
+    }
+  }
   write_counts_files(r);
   write_stats_file(r, start, start_ms, counters, total_reads);
   printf("\nTotal time: %s\n", elapsed_text(now_ms() - start_ms).c_str());  // main.rs:156-164
