@@ -4,7 +4,7 @@
 // SequenceFormat (info.rs:176-187), MaxSeqErrors (info.rs:461-472) and the known-barcode
 // sets of BarcodeConversions (info.rs:338-343).
 #pragma once
-#include <stdint.h>
+#include "bc_intrin.h"
 
 namespace bc {
 
@@ -38,16 +38,18 @@ struct DevGroup {
   uint32_t has_odd;    // set holds refs with 'N' or of a different length (no single-N shortcut)
   uint64_t table_stride;  // multiplier of this group's value (reference index, or base-5 code of a raw
                           // capture) in the mixed-radix tuple key = dense counter index
+  // Device addresses are kept as integers so that a plan is plain bytes (a scheme-specialised
+  // kernel embeds it as a compile-time constant); the accessors below turn them into pointers.
   // kSetDirect: one u32 per N-free capture q1 | q2 << len:
   //   bits 0-15 fix_error's verdict (reference index, kFail16 = None)
   //   bits 16-23 distance of the nearest reference (capped at 255), bit 24 set when only one reference is that near
-  const uint32_t* dtable;
-  const uint32_t* r1;     // reference bit planes (bit i = base i): ASCII bit 1
-  const uint32_t* r2;     //                                          ASCII bit 2
-  const uint32_t* rn;     // 'N' positions of the reference
-  const uint8_t* rlen;    // reference length
-  const uint64_t* hkeys;  // kSetHash: q1 | q2 << 32 of references usable for exact lookup
-  const uint32_t* hvals;  // index or kFail for an empty slot
+  uint64_t dtable_a;
+  uint64_t r1_a;     // reference bit planes (bit i = base i): ASCII bit 1
+  uint64_t r2_a;     //                                          ASCII bit 2
+  uint64_t rn_a;     // 'N' positions of the reference
+  uint64_t rlen_a;   // reference length (u8)
+  uint64_t hkeys_a;  // kSetHash: q1 | q2 << 32 of references usable for exact lookup
+  uint64_t hvals_a;  // index or kFail for an empty slot
   // kSetHash, large sets: pigeonhole seeds.  The capture is cut into seed_nb = max_err + 1 blocks of
   // seed_blen bases; a reference within max_err mismatches equals the capture on at least one block,
   // so only the references filed under the capture's block values need scoring.
@@ -55,9 +57,20 @@ struct DevGroup {
   uint32_t seed_blen;
   uint32_t n_idx;         // plain references (no 'N', length == len) in the index
   uint32_t n_odd;         // the others, always scored
-  const uint32_t* seed_off;   // [seed_nb][4^seed_blen + 1] bucket starts into seed_list rows
-  const uint32_t* seed_list;  // [seed_nb][n_idx] entries {r1, r2, index, 0} (16 B) ordered by block value
-  const uint32_t* odd_list;   // [n_odd]
+  uint64_t seed_off_a;    // [seed_nb][4^seed_blen + 1] bucket starts into seed_list rows
+  uint64_t seed_list_a;   // [seed_nb][n_idx] entries {r1, r2, index, 0} (16 B) ordered by block value
+  uint64_t odd_list_a;    // [n_odd]
+
+  BC_HD const uint32_t* dtable() const { return reinterpret_cast<const uint32_t*>(dtable_a); }
+  BC_HD const uint32_t* r1() const { return reinterpret_cast<const uint32_t*>(r1_a); }
+  BC_HD const uint32_t* r2() const { return reinterpret_cast<const uint32_t*>(r2_a); }
+  BC_HD const uint32_t* rn() const { return reinterpret_cast<const uint32_t*>(rn_a); }
+  BC_HD const uint8_t* rlen() const { return reinterpret_cast<const uint8_t*>(rlen_a); }
+  BC_HD const uint64_t* hkeys() const { return reinterpret_cast<const uint64_t*>(hkeys_a); }
+  BC_HD const uint32_t* hvals() const { return reinterpret_cast<const uint32_t*>(hvals_a); }
+  BC_HD const uint32_t* seed_off() const { return reinterpret_cast<const uint32_t*>(seed_off_a); }
+  BC_HD const uint32_t* seed_list() const { return reinterpret_cast<const uint32_t*>(seed_list_a); }
+  BC_HD const uint32_t* odd_list() const { return reinterpret_cast<const uint32_t*>(odd_list_a); }
 };
 
 struct DevPlan {
@@ -94,6 +107,9 @@ struct DevPlan {
   uint32_t run_thr[kMaxRuns];   // low <=> sum(scores) < thr   (f32-exact, Appendix A Q10)
   DevGroup groups[kMaxGroups];  // sample group first (if any), then counted barcodes in order, then random
 };
+
+constexpr int kNCounters = 8;      // BC_NCOUNTERS
+constexpr int kTotalReads = 6;     // BC_TOTAL_READS
 
 // outcome of one read, in counter order (barcode_count_hip.h BC_*)
 enum Outcome : uint32_t {

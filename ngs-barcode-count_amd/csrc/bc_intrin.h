@@ -2,13 +2,21 @@
 // Under hipcc these are the hardware instructions; the plain-C++ forms exist only so that
 // tests/emu can run the SAME lane logic on the host against the oracle (never a product path).
 #pragma once
+#if defined(__HIPCC_RTC__)
+// run-time compilation (hiprtc): the HIP device builtins are predeclared, the C headers are not
+typedef unsigned char uint8_t;
+typedef unsigned short uint16_t;
+typedef unsigned int uint32_t;
+typedef unsigned long long uint64_t;
+#define BC_HD __device__ __forceinline__
+#else
 #include <stdint.h>
-
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define BC_HD __host__ __device__ __forceinline__
 #else
 #define BC_HD inline
+#endif
 #endif
 
 namespace bc {

@@ -1,0 +1,443 @@
+// bc_kernel.h -- device code of the hot kernel: SequenceParser::parse (parse.rs:53-76) for a batch.
+// Included by bc_engine.hip (generic kernel: the plan is read from device memory) and by the
+// scheme-specialised translation unit the engine compiles at run time with hiprtc (the plan is a
+// compile-time constant, so every shift, offset and loop bound of the scheme becomes an immediate).
+#pragma once
+#include "bc_lane.h"
+
+namespace bc {
+
+constexpr int kTPB = 256;          // reads (lanes) per workgroup
+#ifndef BC_MIN_WAVES
+#define BC_MIN_WAVES 3  // occupancy floor (waves per SIMD) the register allocator must honour
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// wave-level pieces
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t t = (uint32_t)__shfl_xor((int)v, o);
+    v = t < v ? t : v;
+  }
+  return v;
+}
+
+// combines the lanes' partial unique-minimum searches: wave min-reduce of the key, then a vote
+__device__ __forceinline__ uint32_t wave_verdict(const Nearest& s, uint32_t max_err) {
+  const uint32_t kmin = wave_min_u32(s.key);
+  const unsigned long long holders = __ballot(s.key == kmin);
+  const int first = __ffsll(holders) - 1;
+  const uint32_t cnt = (uint32_t)__shfl((int)s.count, first);
+  const uint32_t idx = (uint32_t)__shfl((int)s.idx, first);
+  const bool unique = __popcll(holders) == 1 && kmin != 0xFFFFFFFFu;
+  return unique ? nearest_result(kmin, idx, cnt, max_err) : kFail;
+}
+
+// fix_error (parse.rs:553-593) for ONE capture by the whole wavefront: every lane scores the
+// references j = lane, lane+64, ...; a wavefront min-reduce plus a vote decides best / ambiguous.
+// use_exact: a reference that IS the capture wins outright (AHashSet::contains, parse.rs:457/489).
+__device__ __forceinline__ uint32_t wave_fix_error(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t qn, uint32_t qx,
+                                                   bool use_exact) {
+  const uint32_t lane = __lane_id();
+  Nearest s;
+  nearest_init(s);
+  for (uint32_t j = lane; j < G.n_refs; j += 64) {
+    bool ex;
+    const uint32_t d = ref_distance(q1, q2, qn, qx, G.len, G.r1()[j], G.r2()[j], G.rn()[j], G.rlen()[j], ex);
+    nearest_add(s, d, j, ex && use_exact);
+  }
+  return wave_verdict(s, G.max_err);
+}
+
+// The same verdict for a large set through the pigeonhole seed index: only references that equal
+// the capture on one of its max_err+1 blocks can be within the budget, and every reference within
+// the budget is among them, so best / ambiguous come out exactly as from the full scan.
+// The whole wavefront walks the capture's buckets, 256 entries (four 1-KiB loads) in flight; the
+// entries carry the reference planes, so there is one memory round trip per batch.
+// The capture must be free of 'N' / foreign bytes.
+// Returns the smallest key (distance + 1, 0 for the capture itself), whether exactly one reference
+// has it, and that reference.
+__device__ __forceinline__ void wave_seeded_min(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t& kmin_out,
+                                                bool& unique_out, uint32_t& idx_out) {
+  const uint32_t nb = G.seed_nb, blen = G.seed_blen, bm = (1u << blen) - 1u;
+  const uint32_t nbk = 1u << (2 * blen);
+  const uint32_t lane = __lane_id();
+  const uint4* entries = reinterpret_cast<const uint4*>(G.seed_list());
+  Nearest s;
+  nearest_init(s);
+  for (uint32_t b = 0; b < nb; ++b) {
+    const uint32_t val = ((q1 >> (b * blen)) & bm) | (((q2 >> (b * blen)) & bm) << blen);
+    const uint32_t* off = G.seed_off() + (size_t)b * (nbk + 1);
+    const uint32_t beg = off[val], end = off[val + 1];
+    const uint4* list = entries + (size_t)b * G.n_idx;
+    // blocks before b on which a reference may not equal the capture (it was scored there)
+    for (uint32_t i0 = beg; i0 < end; i0 += 256) {
+      uint4 e[4];
+      bool on[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t i = i0 + 64u * k + lane;
+        on[k] = i < end;
+        e[k] = list[on[k] ? i : beg];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t diff = (q1 ^ e[k].x) | (q2 ^ e[k].y);
+        bool earlier = false;
+        for (uint32_t p = 0; p < b; ++p) earlier = earlier || ((diff >> (p * blen)) & bm) == 0u;
+        if (on[k] && !earlier) nearest_add(s, popc(diff), e[k].z, diff == 0u);
+      }
+    }
+    // A reference with d mismatches has at most d spoiled blocks, so it has shown up by the time
+    // blocks 0..d are done: once the best distance so far is <= b nothing nearer or equally near
+    // can still be hiding in the later blocks.
+    const uint32_t kmin = wave_min_u32(s.key);
+    if (kmin != 0xFFFFFFFFu && kmin <= b + 1u) break;
+  }
+  for (uint32_t i = lane; i < G.n_odd; i += 64) {
+    const uint32_t j = G.odd_list()[i];
+    bool ex;
+    const uint32_t d = ref_distance(q1, q2, 0u, 0u, G.len, G.r1()[j], G.r2()[j], G.rn()[j], G.rlen()[j], ex);
+    nearest_add(s, d, j, ex);
+  }
+  const uint32_t kmin = wave_min_u32(s.key);
+  const unsigned long long holders = __ballot(s.key == kmin);
+  const int first = __ffsll(holders) - 1;
+  kmin_out = kmin;
+  unique_out = __popcll(holders) == 1 && (uint32_t)__shfl((int)s.count, first) == 1u && kmin != 0xFFFFFFFFu;
+  idx_out = (uint32_t)__shfl((int)s.idx, first);
+}
+
+// A capture with up to two 'N's against plain references: 'N' is free (parse.rs:569), so its
+// distance to a reference is that of the capture with each N replaced by the reference's base
+// there.  The nearest references of the capture are therefore those of its 4 (16) substitutions
+// at the smallest of their minimum distances, and the match is unique iff exactly one substitution
+// reaches that distance and does so uniquely (the argument of single_n_lookup, bc_lane.h).
+__device__ __forceinline__ uint32_t wave_fix_error_seeded(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t qn) {
+  const uint32_t n_n = popc(qn);
+  const uint32_t p0 = n_n ? ctz(qn) : 0u;
+  const uint32_t p1 = n_n > 1 ? ctz(qn & (qn - 1u)) : 0u;
+  const uint32_t combos = 1u << (2u * n_n);
+  const uint32_t b1 = q1 & ~qn, b2 = q2 & ~qn;
+  uint32_t best = 0xFFFFFFFFu, res = kFail;
+  bool ok = false;
+  for (uint32_t c = 0; c < combos; ++c) {
+    uint32_t s1 = b1, s2 = b2;
+    if (n_n > 0) {
+      s1 |= (c & 1u) << p0;
+      s2 |= ((c >> 1) & 1u) << p0;
+    }
+    if (n_n > 1) {
+      s1 |= ((c >> 2) & 1u) << p1;
+      s2 |= ((c >> 3) & 1u) << p1;
+    }
+    uint32_t k, idx;
+    bool uniq;
+    wave_seeded_min(G, s1, s2, k, uniq, idx);
+    if (k < best) {
+      best = k;
+      ok = uniq;
+      res = idx;
+    } else if (k == best) {
+      ok = false;
+    }
+  }
+  return (ok && best != 0xFFFFFFFFu && (best == 0u || best - 1u <= G.max_err)) ? res : kFail;
+}
+
+// Wave-private LDS tile: each wavefront stages the 64 reads it owns (64*stride contiguous bytes of
+// the batch, 16 B per lane and instruction) and never needs a workgroup barrier to use them: LDS
+// executes one wave's instructions in order, so only the compiler has to be told not to reorder.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ void stage_tile(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t bytes,
+                                           uint32_t region, uint8_t pad, uint32_t lane) {
+  const uint4* g = reinterpret_cast<const uint4*>(src);
+  uint4* d = reinterpret_cast<uint4*>(dst);
+  const uint32_t n16 = bytes >> 4;
+  for (uint32_t i0 = 0; i0 < n16; i0 += 256) {  // four independent 1-KiB wave loads in flight
+    const uint32_t ia = i0 + lane, ib = ia + 64u, ic = ia + 128u, id = ia + 192u;
+    const uint32_t last = n16 - 1u;
+    const uint4 ra = g[ia < n16 ? ia : last];
+    const uint4 rb = g[ib < n16 ? ib : last];
+    const uint4 rc = g[ic < n16 ? ic : last];
+    const uint4 rd = g[id < n16 ? id : last];
+    if (ia < n16) d[ia] = ra;
+    if (ib < n16) d[ib] = rb;
+    if (ic < n16) d[ic] = rc;
+    if (id < n16) d[id] = rd;
+  }
+  for (uint32_t i = (n16 << 4) + lane; i < bytes; i += 64) dst[i] = src[i];
+  // bytes past the reads that the lane code may touch: plain values
+  for (uint32_t i = bytes + lane; i < region; i += 64) dst[i] = pad;
+}
+
+// ---- device hash set of 64-bit keys (the AHashSet<String> per tuple of info.rs:663, flattened) ----
+constexpr unsigned long long kEmptyKey = ~0ull;
+
+// true when the key was not in the set before
+__device__ __forceinline__ bool set_insert(unsigned long long* __restrict__ slots, uint64_t mask, uint64_t key) {
+  uint64_t h = hash64(key) & mask;
+  for (;;) {
+    const unsigned long long old = atomicCAS(&slots[h], kEmptyKey, (unsigned long long)key);
+    if (old == kEmptyKey) return true;
+    if (old == key) return false;
+    h = (h + 1) & mask;
+  }
+}
+
+// slot of the key in a hash map, inserting it when absent
+__device__ __forceinline__ uint64_t map_slot(unsigned long long* __restrict__ slots, uint64_t mask, uint64_t key) {
+  uint64_t h = hash64(key) & mask;
+  for (;;) {
+    const unsigned long long old = atomicCAS(&slots[h], kEmptyKey, (unsigned long long)key);
+    if (old == kEmptyKey || old == key) return h;
+    h = (h + 1) & mask;
+  }
+}
+
+// Asynchronous tile fetch: global -> LDS without passing through registers
+// (global_load_lds_dwordx4: every lane moves 16 bytes, the wave 1 KiB per instruction, destination
+// = wave-uniform LDS base + lane * 16).  `bytes` must be a multiple of 16 (a full 64-read tile is).
+__device__ __forceinline__ void dma_tile(uint8_t* lds_dst, const uint8_t* __restrict__ src, uint32_t bytes, uint32_t lane) {
+  for (uint32_t off0 = 0; off0 < bytes; off0 += 1024u) {
+    const uint32_t off = off0 + lane * 16u;
+    if (off < bytes)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off),
+                                       (__attribute__((address_space(3))) void*)(lds_dst + off0), 16, 0, 0);
+  }
+}
+
+// waits until at most `keep` of this wave's youngest vector-memory operations are outstanding
+// (they complete in issue order, so everything older has landed)
+__device__ __forceinline__ void wait_vm_keep(uint32_t keep) {
+  switch (keep) {  // the count is an immediate of the instruction
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+    case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+    case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+    case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+    case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+    case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
+    case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+struct DeviceOps {
+  uint8_t* tile;          // this wave's LDS region for sequence lines
+  uint8_t* qtile;         // ... for quality lines (pipelined fetch) -- equals `tile` when fetched on demand
+  const uint8_t* qsrc;    // this tile's quality lines in global memory
+  const uint8_t* next_seq;  // next full tile of this wave (nullptr: none, or a partial one fetched synchronously)
+  uint32_t bytes, region, lane;
+  uint32_t chunks;        // 1-KiB fetch instructions per full tile
+  uint32_t pending_add;   // 1 while the previous tile's counter atomic may still be in flight
+  bool qual_async;        // this tile's quality lines were requested ahead of time
+
+  __device__ __forceinline__ bool any(bool c) const { return __any(c) != 0; }
+  // the sequence bytes are dead once the planes are built: the next tile's sequence lines can land
+  __device__ __forceinline__ void sequence_consumed() const {
+    wave_lds_fence();
+    if (next_seq) dma_tile(tile, next_seq, 64u * (bytes_per_read()), lane);
+  }
+  __device__ __forceinline__ uint32_t bytes_per_read() const { return stride_; }
+  uint32_t stride_;
+  __device__ __forceinline__ const uint32_t* stage_quality() const {
+    if (qual_async) {
+      // issued before this tile's sequence fetch of the next tile: everything but that fetch has landed
+      wait_vm_keep((next_seq ? chunks : 0u) + pending_add);
+      wave_lds_fence();
+      return reinterpret_cast<const uint32_t*>(qtile);
+    }
+    wave_lds_fence();
+    stage_tile(qtile, qsrc, bytes, region, (uint8_t)'I', lane);
+    wave_lds_fence();
+    return reinterpret_cast<const uint32_t*>(qtile);
+  }
+  // every lane calls this; lanes with `need` get their capture resolved one after the other
+  __device__ __forceinline__ uint32_t nearest(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t qn, uint32_t qx,
+                                              bool need) const {
+    uint32_t out = kFail;
+    unsigned long long todo = __ballot(need);
+    while (todo) {
+      const int src = __ffsll(todo) - 1;
+      todo &= todo - 1;
+      const uint32_t b1 = (uint32_t)__shfl((int)q1, src);
+      const uint32_t b2 = (uint32_t)__shfl((int)q2, src);
+      const uint32_t bn = (uint32_t)__shfl((int)qn, src);
+      const uint32_t bx = (uint32_t)__shfl((int)qx, src);
+      // the seed index answers captures with at most two 'N's when every reference is plain
+      const bool seeded = G.seed_nb && bx == 0u && G.n_odd == 0u && __popc(bn) <= 2;
+      const uint32_t r = seeded ? wave_fix_error_seeded(G, b1, b2, bn) : wave_fix_error(G, b1, b2, bn, bx, true);
+      if (lane == (uint32_t)src) out = r;
+    }
+    return out;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// the hot kernel: SequenceParser::parse, 64 reads per wavefront, 4 wavefronts per workgroup
+// ------------------------------------------------------------------------------------------------
+template <int NW, int NWW>
+__device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_t* __restrict__ seq,
+                                                 const uint8_t* __restrict__ qual, const uint16_t* __restrict__ lens,
+                                                 uint32_t stride, uint32_t read_len, uint32_t nd, uint64_t n_reads,
+                                                 uint32_t region, uint32_t* __restrict__ table,
+                                                 unsigned long long* __restrict__ slots, uint32_t* __restrict__ vals,
+                                                 uint64_t smask, unsigned long long* __restrict__ counters,
+                                                 uint8_t* __restrict__ trace_outcome, uint64_t* __restrict__ trace_idx) {
+  extern __shared__ uint4 smem[];
+  __shared__ uint32_t s_cnt[kNCounters];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = tid >> 6;
+  if (tid < kNCounters) s_cnt[tid] = 0;
+
+  const bool with_qual = pl.quality_on && !(pl.ablate & 0x8u);
+  DeviceOps ops;
+  // per wave: one region for sequence lines and, with the quality filter on, one for quality lines
+  ops.tile = reinterpret_cast<uint8_t*>(smem) + wave * region * (with_qual ? 2u : 1u);
+  ops.qtile = ops.tile + (with_qual ? region : 0u);
+  ops.region = region;
+  ops.lane = lane;
+  ops.stride_ = stride;
+  const uint32_t full_bytes = 64u * stride;
+  ops.chunks = (full_bytes + 1023u) / 1024u;
+  ops.pending_add = 0;
+
+  // Persistent wavefronts: wave-tile t = 64 consecutive reads; this wave takes tiles
+  // gid, gid + G, gid + 2G, ...  No workgroup barrier inside the loop; the outcome counters stay in
+  // registers until the very end, so the six global counters see one add per workgroup.
+  // Software pipeline: while tile t is being matched, the sequence lines of the wave's next tile
+  // are already on their way into the sequence region (free once t's bit planes exist), and t's
+  // quality lines were requested at the end of the previous iteration.
+  const uint64_t n_tiles = (n_reads + 63u) >> 6;
+  const uint64_t n_full = n_reads >> 6;  // tiles with all 64 reads
+  const uint64_t n_waves = (uint64_t)gridDim.x * (kTPB / 64);
+  uint32_t acc_cnt[kNCounters];
+#pragma unroll
+  for (int k = 0; k < kNCounters; ++k) acc_cnt[k] = 0;
+  // slack bytes behind the reads that the lane code may touch: plain values, written once
+  for (uint32_t i = full_bytes + lane; i < region; i += 64) {
+    ops.tile[i] = 'A';
+    if (with_qual) ops.qtile[i] = 'I';
+  }
+  uint64_t t = (uint64_t)blockIdx.x * (kTPB / 64) + wave;
+  bool seq_ready = false, qual_ready = false;  // requested ahead of time
+  if (t < n_full && !(pl.ablate & 0x80u)) {
+    dma_tile(ops.tile, seq + (t << 6) * stride, full_bytes, lane);
+    seq_ready = true;
+    if (with_qual) {
+      dma_tile(ops.qtile, qual + (t << 6) * stride, full_bytes, lane);
+      qual_ready = true;
+    }
+  }
+  for (; t < n_tiles; t += n_waves) {
+    const uint64_t wfirst = t << 6;
+    const uint32_t n_w = n_reads - wfirst < 64u ? (uint32_t)(n_reads - wfirst) : 64u;
+    const uint64_t goff = wfirst * stride;  // multiple of 64 bytes: 16-byte aligned
+    const uint64_t tn = t + n_waves;
+    const bool next_full = tn < n_full && !(pl.ablate & 0x80u);
+    ops.qsrc = qual + goff;
+    ops.bytes = n_w * stride;
+    ops.next_seq = next_full ? seq + (tn << 6) * stride : nullptr;
+    ops.qual_async = qual_ready;
+    if (seq_ready) {
+      // outstanding, oldest first: [this tile's sequence lines] [its quality lines] [the previous tile's
+      // counter atomic] -- only the first must have landed
+      wait_vm_keep((qual_ready ? ops.chunks : 0u) + ops.pending_add);
+      wave_lds_fence();
+    } else {
+      wave_lds_fence();  // the previous tile's last LDS reads are done before the tile is overwritten
+      if (!(pl.ablate & 0x80u)) stage_tile(ops.tile, seq + goff, ops.bytes, full_bytes, (uint8_t)'A', lane);
+      wave_lds_fence();
+    }
+
+    const bool active = lane < n_w;
+    uint32_t len = 0;
+    if (active) len = lens ? (uint32_t)lens[wfirst + lane] : read_len;
+    const uint32_t base = (active ? lane : 0u) * stride;
+    const ReadResult r =
+        process_read<DeviceOps, NW, NWW>(pl, ops, reinterpret_cast<const uint32_t*>(ops.tile), base, len, nd, active);
+
+    uint32_t outcome = r.outcome;
+    if (pl.has_random) {
+      // Results::add_count with a random barcode (info.rs:770-802): insert (tuple, random) into the
+      // set; an element already present makes the read a duplicate (parse.rs:65-69)
+      if (active && outcome == kMatched && !set_insert(slots, smask, r.dense_idx * pl.rspace + r.rcode))
+        outcome = kDuplicate;
+    }
+    // outcome counters (SequenceErrors, info.rs:16-139)
+#pragma unroll
+    for (uint32_t k = 0; k < kNCounters; ++k) {
+      if (k == kTotalReads) continue;
+      acc_cnt[k] += (uint32_t)__popcll(__ballot(active && outcome == k));
+    }
+    acc_cnt[kTotalReads] += n_w;
+    if (trace_outcome && active) {
+      trace_outcome[wfirst + lane] = (uint8_t)outcome;
+      trace_idx[wfirst + lane] = pl.has_random ? r.dense_idx * pl.rspace + r.rcode : r.dense_idx;
+    }
+    // the quality region is free: request the next tile's quality lines (they have until that tile's
+    // quality stage to arrive)
+    seq_ready = next_full;
+    qual_ready = false;
+    if (next_full && with_qual) {
+      wave_lds_fence();
+      dma_tile(ops.qtile, qual + (tn << 6) * stride, full_bytes, lane);
+      qual_ready = true;
+    }
+    // Results::add_count (info.rs:761-767): one no-return atomic into the dense counter table, or,
+    // when captures are kept raw, into the hash map slot of the tuple key.  Issued last so that the
+    // fetches above are older: nothing in the next tile has to wait for the atomic to retire.
+    ops.pending_add = 0;
+    if (!pl.has_random) {
+      const bool add = active && outcome == kMatched && !pl.discard_counts && !(pl.ablate & 0x4u);
+      if (__any(add)) {
+        if (add) {
+          if (pl.sparse)
+            atomicAdd(&vals[map_slot(slots, smask, r.dense_idx)], 1u);
+          else
+            atomicAdd(&table[r.dense_idx], 1u);
+        }
+        ops.pending_add = pl.sparse ? 0u : 1u;  // map_slot's compare-and-swap is waited for; the add is not
+      }
+    }
+  }
+
+  __syncthreads();  // s_cnt zeroed
+  if (lane == 0) {
+#pragma unroll
+    for (uint32_t k = 0; k < kNCounters; ++k)
+      if (acc_cnt[k]) atomicAdd(&s_cnt[k], acc_cnt[k]);
+  }
+  __syncthreads();
+  if (tid < kNCounters) {
+    const uint32_t v = s_cnt[tid];
+    if (v) atomicAdd(&counters[tid], (unsigned long long)v);
+  }
+}
+
+}  // namespace bc

@@ -525,7 +525,7 @@ BC_HD uint32_t dtable_entry(const DevGroup& G, uint32_t q) {
   nearest_init(s);
   for (uint32_t j = 0; j < G.n_refs; ++j) {
     bool ex;
-    const uint32_t d = ref_distance(q1, q2, 0u, 0u, G.len, G.r1[j], G.r2[j], G.rn[j], G.rlen[j], ex);
+    const uint32_t d = ref_distance(q1, q2, 0u, 0u, G.len, G.r1()[j], G.r2()[j], G.rn()[j], G.rlen()[j], ex);
     nearest_add(s, d, j, ex);
   }
   const uint32_t r = nearest_result(s.key, s.idx, s.count, G.max_err);
@@ -546,7 +546,7 @@ BC_HD uint32_t single_n_lookup(const DevGroup& G, uint32_t q1, uint32_t q2, uint
   bool ok = false;
 #pragma unroll
   for (uint32_t b = 0; b < 4; ++b) {
-    const uint32_t t = G.dtable[(b1 | ((b & 1u) << k)) | ((b2 | ((b >> 1) << k)) << G.len)];
+    const uint32_t t = G.dtable()[(b1 | ((b & 1u) << k)) | ((b2 | ((b >> 1) << k)) << G.len)];
     const uint32_t d = (t >> 16) & 0xFFu;
     if (d < best) {
       best = d;
@@ -569,9 +569,10 @@ struct ReadResult {
 // Ops must provide:
 //   bool any(bool)                               -- wave vote
 //   uint32_t nearest(const DevGroup&, q1,q2,qn,qx, bool need) -- cooperative Hamming search, every lane calls it
-//   const uint32_t* stage_quality()              -- called once, by every lane, after the last use of the
-//                                                   sequence bytes: returns where the quality lines are
-//                                                   (the GPU reloads the wave's LDS tile with them)
+//   void sequence_consumed()                     -- called once, by every lane, after the last read of the
+//                                                   sequence bytes (the GPU starts fetching the next tile)
+//   const uint32_t* stage_quality()              -- called once, by every lane, when the quality filter is
+//                                                   on: returns where the quality lines are
 // NW = 32-base words per read; NWW = words of candidate offsets / repair windows (len - L + 1 <= 32*NWW)
 template <class Ops, int NW, int NWW>
 BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32, uint32_t base, uint32_t len,
@@ -602,6 +603,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
     for (int w = 0; w < NW; ++w) h |= hi[w] & inr[w];
     unsupported = h != 0u;  // non-ASCII: the reference's char positions no longer equal byte positions
   }
+  ops.sequence_consumed();
 #pragma unroll
   for (int w = 0; w < NW; ++w) {
     P.pn[w] &= inr[w];
@@ -678,7 +680,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
           if (pre_ok) {
             if (G.mode == kSetDirect) {
               if (clean) {
-                const uint32_t t = G.dtable[q1[u] | (q2[u] << G.len)] & 0xFFFFu;
+                const uint32_t t = G.dtable()[q1[u] | (q2[u] << G.len)] & 0xFFFFu;
                 r[u] = t == (uint32_t)kFail16 ? kFail : t;
               } else if (qx[u] == 0u && !G.has_odd && (qn[u] & (qn[u] - 1u)) == 0u && !(pl.ablate & 0x100u)) {
                 r[u] = single_n_lookup(G, q1[u], q2[u], qn[u]);
@@ -691,9 +693,9 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
                 const uint64_t key = (uint64_t)q1[u] | ((uint64_t)q2[u] << 32);
                 uint32_t h = (uint32_t)hash64(key) & G.hmask;
                 for (;;) {
-                  const uint32_t v = G.hvals[h];
+                  const uint32_t v = G.hvals()[h];
                   if (v == kFail) break;
-                  if (G.hkeys[h] == key) {
+                  if (G.hkeys()[h] == key) {
                     r[u] = v;
                     need[u] = false;
                     break;

@@ -17,6 +17,7 @@ namespace {
 struct HostOps {
   const uint32_t* qual32 = nullptr;
   const uint32_t* stage_quality() const { return qual32; }
+  void sequence_consumed() const {}
   bool any(bool c) const { return c; }
   uint32_t nearest(const bc::DevGroup& G, uint32_t q1, uint32_t q2, uint32_t qn, uint32_t qx, bool need) const {
     if (!need) return bc::kFail;
@@ -24,7 +25,7 @@ struct HostOps {
     bc::nearest_init(s);
     for (uint32_t j = 0; j < G.n_refs; ++j) {
       bool ex;
-      const uint32_t d = bc::ref_distance(q1, q2, qn, qx, G.len, G.r1[j], G.r2[j], G.rn[j], G.rlen[j], ex);
+      const uint32_t d = bc::ref_distance(q1, q2, qn, qx, G.len, G.r1()[j], G.r2()[j], G.rn()[j], G.rlen()[j], ex);
       bc::nearest_add(s, d, j, ex);
     }
     return bc::nearest_result(s.key, s.idx, s.count, G.max_err);
@@ -74,17 +75,17 @@ void* emu_plan_create(const bc_plan* p) {
   for (uint32_t g = 0; g < E->h.plan.n_groups; ++g) {
     bc::DevGroup& G = E->h.plan.groups[g];
     bc::HostSet& H = E->h.sets[g];
-    G.r1 = H.r1.data();
-    G.r2 = H.r2.data();
-    G.rn = H.rn.data();
-    G.rlen = H.rlen.data();
-    G.hkeys = H.hkeys.data();
-    G.hvals = H.hvals.data();
+    G.r1_a = (uint64_t)(uintptr_t)H.r1.data();
+    G.r2_a = (uint64_t)(uintptr_t)H.r2.data();
+    G.rn_a = (uint64_t)(uintptr_t)H.rn.data();
+    G.rlen_a = (uint64_t)(uintptr_t)H.rlen.data();
+    G.hkeys_a = (uint64_t)(uintptr_t)H.hkeys.data();
+    G.hvals_a = (uint64_t)(uintptr_t)H.hvals.data();
     if (G.mode == bc::kSetDirect) {
       const uint32_t nq = 1u << (2 * G.len);
       E->dtables[g].resize(nq);
       for (uint32_t q = 0; q < nq; ++q) E->dtables[g][q] = bc::dtable_entry(G, q);
-      G.dtable = E->dtables[g].data();
+      G.dtable_a = (uint64_t)(uintptr_t)E->dtables[g].data();
     }
   }
   return E;
