@@ -195,7 +195,7 @@ def main():
                    "read_len": R, "parallelism": "reads sharded over %d GPU(s); 1 RCCL sum-reduce of the counter table" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "alg_bytes_per_launch": b_alg * n, "kernel": "match_count_kernel<4,2>",
+                     "alg_bytes_per_launch": b_alg * n, "kernel": eng.kernel_name(),
                      "kernel_avg_ms": avg_ms, "launches": launches, "alg_bytes_per_read": b_alg,
                      "kernel_reads_per_s": n / (avg_ms * 1e-3) if avg_ms > 0 else 0.0,
                      "frac_of_measured_copy_ceiling_6290": achieved / 6290.0},

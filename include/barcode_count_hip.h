@@ -172,6 +172,22 @@ int bc_engine_trace(bc_engine *e, void *d_outcome_u8, void *d_index_u64);
 /* HIP-event timing of the match/count kernel on the engine's stream (for the roofline) */
 int bc_engine_timing(bc_engine *e, int enable);
 int bc_engine_kernel_ms(bc_engine *e, double *total_ms, uint64_t *launches);
+/* Which kernel the last submit launched: "match_count_kernel<NW,NWW>" (the generic one, any plan) or
+ * "bc_jit_match_count<NW,NWW>" (the one specialised to this plan's scheme); "" before the first submit. */
+const char *bc_engine_kernel_name(bc_engine *e);
+
+/* Scheme-specialised kernels.  For batches of 2^20 reads or more an engine runs a kernel compiled for
+ * its plan's scheme (offsets, shift programs, thresholds and set sizes as immediates).  The code
+ * object is looked up in jit_cache/ next to the library and in $BC_JIT_CACHE; if absent it is
+ * compiled on first use (ROCm's hipcc as a child process, else hiprtc in-process) and stored there.
+ * When neither is available the engine says so on stderr and keeps using the generic kernel -- same
+ * results, about 15 % slower.  Environment: BC_JIT=0 (never) | 1 (default) | force (any batch
+ * size) | cached (cache hits only, never compile).
+ * bc_plan_precompile builds the kernel ahead of time without touching a GPU: nw = 32-base words per
+ * read (4 covers reads up to 128 bases; only nw = 4 is specialised today), nww = words of candidate
+ * offsets ((read_len - scheme_len + 1 + 31) / 32), with_lens = per-read lengths will be passed,
+ * cache_dir NULL = next to the library. */
+int bc_plan_precompile(const bc_plan *p, int nw, int nww, int with_lens, const char *cache_dir);
 
 /* fix_error (parse.rs:553-593) on the device: nearest unique candidate under Hamming distance
  * with 'N' wildcards, common-prefix compare.  Returns the candidate index, -1 for None,

@@ -205,6 +205,9 @@ class Engine:
     def timing(self, enable=True):
         _check(self._lib, self._lib.bc_engine_timing(self._e, 1 if enable else 0))
 
+    def kernel_name(self):
+        return self._lib.bc_engine_kernel_name(self._e).decode()
+
     def kernel_ms(self):
         ms, n = C.c_double(), C.c_uint64()
         _check(self._lib, self._lib.bc_engine_kernel_ms(self._e, C.byref(ms), C.byref(n)))
@@ -281,6 +284,14 @@ def make_set(seed, n, k, min_dist=1, lib=None):
     _check(lib, rc)
     raw = buf.raw
     return [raw[i * (k + 1):i * (k + 1) + k].decode() for i in range(n)]
+
+
+def precompile(plan, nw=4, nww=2, lens=False, cache_dir=None):
+    """Builds the scheme-specialised match kernel of a plan ahead of time (no GPU needed) into the kernel
+    cache (default: jit_cache/ next to the library), so that engines of this plan find it ready.
+    nw = 32-base words per read (4: reads up to 128 bases), nww = words of candidate offsets."""
+    lib = plan._lib
+    _check(lib, lib.bc_plan_precompile(plan._p, nw, nww, 1 if lens else 0, cache_dir.encode() if cache_dir else None))
 
 
 def fix_error(mismatch_seq, possible_seqs, mismatches, device=0, lib=None):

@@ -6,15 +6,32 @@
 #pragma once
 #include "bc_intrin.h"
 
+#ifdef BC_JIT_TU
+// A scheme-specialised kernel embeds the plan as a constant but takes the table addresses from this
+// array, which the engine fills after loading the code object: the compiled code then depends only
+// on the scheme, the budgets and the set sizes, and can be cached across runs.
+extern "C" __constant__ uint64_t bc_jit_addr[];
+#define BC_ADDR(field, k) bc_jit_addr[index * kAddrPerGroup + (k)]
+#define BC_PLAN_ADDR(field, k) bc_jit_addr[kMaxGroups * kAddrPerGroup + (k)]
+#else
+#define BC_ADDR(field, k) field
+#define BC_PLAN_ADDR(field, k) field
+#endif
+
 namespace bc {
 
-constexpr int kMaxGroups = 18;    // sample + 16 counted barcodes + random
+constexpr int kMaxGroups = 18;
+constexpr int kAddrPerGroup = 10;  // address fields of a DevGroup, in declaration order
+constexpr int kPlanAddrs = 1;      // ... of the DevPlan itself    // sample + 16 counted barcodes + random
 constexpr int kMaxEntries = 160;  // program entries per position class (up to three positions each)
 constexpr int kMaxRuns = 40;      // quality runs of regions_string
 constexpr int kClasses = 5;       // A, C, T, G constants + scheme-N ([AGCT]) positions
 constexpr int kMaxNW = 10;        // 32-base words per read: reads up to 320 bases
 constexpr uint32_t kFail = 0xFFFFFFFFu;
 constexpr uint16_t kFail16 = 0xFFFFu;
+constexpr uint32_t kLhashMul1 = 0x9E3779B1u;
+constexpr uint32_t kLhashMul2 = 0x85EBCA6Bu;
+constexpr uint32_t kLhashMaxVec = 2048;  // 32 KiB of LDS per workgroup at most
 
 // letter code of an ASCII base: (c >> 1) & 3  ->  A=0 C=1 T=2 G=3
 enum { kCodeA = 0, kCodeC = 1, kCodeT = 2, kCodeG = 3, kClassFmtN = 4 };
@@ -60,17 +77,28 @@ struct DevGroup {
   uint64_t seed_off_a;    // [seed_nb][4^seed_blen + 1] bucket starts into seed_list rows
   uint64_t seed_list_a;   // [seed_nb][n_idx] entries {r1, r2, index, 0} (16 B) ordered by block value
   uint64_t odd_list_a;    // [n_odd]
+  // kSetDirect, small sets: the plain references also sit in an LDS-resident exact-match table of
+  // 4-entry buckets, entry = capture key << ibits | reference index with ibits = 32 - 2 * len.  A key
+  // lives in one of its two buckets (two multiplicative hashes), so a lookup is two 16-byte LDS reads.
+  // A capture that is a reference is answered from LDS; a capture that is not falls through to the
+  // dtable gather (or, when no mismatch is allowed, fails right away).  Unused slots hold copies of
+  // a real entry.  lhash_complete: every plain reference found a slot, so "not in the table" proves
+  // "not a reference" (it always does unless the builder ran out of moves).
+  uint32_t lhash_shift;     // bucket = (key * kLhashMul{1,2}) >> lhash_shift; 0: no LDS table for this group
+  uint32_t lhash_off;       // first bucket of this group in the workgroup's table area (16-byte units)
+  uint32_t lhash_complete;
+  uint32_t index;           // position in DevPlan::groups
 
-  BC_HD const uint32_t* dtable() const { return reinterpret_cast<const uint32_t*>(dtable_a); }
-  BC_HD const uint32_t* r1() const { return reinterpret_cast<const uint32_t*>(r1_a); }
-  BC_HD const uint32_t* r2() const { return reinterpret_cast<const uint32_t*>(r2_a); }
-  BC_HD const uint32_t* rn() const { return reinterpret_cast<const uint32_t*>(rn_a); }
-  BC_HD const uint8_t* rlen() const { return reinterpret_cast<const uint8_t*>(rlen_a); }
-  BC_HD const uint64_t* hkeys() const { return reinterpret_cast<const uint64_t*>(hkeys_a); }
-  BC_HD const uint32_t* hvals() const { return reinterpret_cast<const uint32_t*>(hvals_a); }
-  BC_HD const uint32_t* seed_off() const { return reinterpret_cast<const uint32_t*>(seed_off_a); }
-  BC_HD const uint32_t* seed_list() const { return reinterpret_cast<const uint32_t*>(seed_list_a); }
-  BC_HD const uint32_t* odd_list() const { return reinterpret_cast<const uint32_t*>(odd_list_a); }
+  BC_HD const BC_GLOBAL uint32_t* dtable() const { return reinterpret_cast<const BC_GLOBAL uint32_t*>(BC_ADDR(dtable_a, 0)); }
+  BC_HD const BC_GLOBAL uint32_t* r1() const { return reinterpret_cast<const BC_GLOBAL uint32_t*>(BC_ADDR(r1_a, 1)); }
+  BC_HD const BC_GLOBAL uint32_t* r2() const { return reinterpret_cast<const BC_GLOBAL uint32_t*>(BC_ADDR(r2_a, 2)); }
+  BC_HD const BC_GLOBAL uint32_t* rn() const { return reinterpret_cast<const BC_GLOBAL uint32_t*>(BC_ADDR(rn_a, 3)); }
+  BC_HD const BC_GLOBAL uint8_t* rlen() const { return reinterpret_cast<const BC_GLOBAL uint8_t*>(BC_ADDR(rlen_a, 4)); }
+  BC_HD const BC_GLOBAL uint64_t* hkeys() const { return reinterpret_cast<const BC_GLOBAL uint64_t*>(BC_ADDR(hkeys_a, 5)); }
+  BC_HD const BC_GLOBAL uint32_t* hvals() const { return reinterpret_cast<const BC_GLOBAL uint32_t*>(BC_ADDR(hvals_a, 6)); }
+  BC_HD const BC_GLOBAL uint32_t* seed_off() const { return reinterpret_cast<const BC_GLOBAL uint32_t*>(BC_ADDR(seed_off_a, 7)); }
+  BC_HD const BC_GLOBAL uint32_t* seed_list() const { return reinterpret_cast<const BC_GLOBAL uint32_t*>(BC_ADDR(seed_list_a, 8)); }
+  BC_HD const BC_GLOBAL uint32_t* odd_list() const { return reinterpret_cast<const BC_GLOBAL uint32_t*>(BC_ADDR(odd_list_a, 9)); }
 };
 
 struct DevPlan {
@@ -89,6 +117,8 @@ struct DevPlan {
   uint32_t sparse;      // some group has no known set: its capture's base-5 code is part of the key and
                         // the (then astronomically large) key space is held in a hash map, not a table
   uint64_t rspace;      // 5^rnd_len: key = dense_idx * rspace + code
+  uint32_t lhash_vec;   // uint4s of the LDS exact-match area (0: none); image of it at lhash_a
+  uint64_t lhash_a;
   uint32_t ablate;      // perf-debug only (env BC_ABLATE): bit mask of phases to skip; results are then wrong
   // Per position class a program that walks the class's format positions in ascending order,
   // shifting the class vector right by the distance to the next position (0..31 per shift).
@@ -106,6 +136,8 @@ struct DevPlan {
   uint32_t run_len[kMaxRuns];
   uint32_t run_thr[kMaxRuns];   // low <=> sum(scores) < thr   (f32-exact, Appendix A Q10)
   DevGroup groups[kMaxGroups];  // sample group first (if any), then counted barcodes in order, then random
+
+  BC_HD uint64_t lhash_image() const { return BC_PLAN_ADDR(lhash_a, 0); }
 };
 
 constexpr int kNCounters = 8;      // BC_NCOUNTERS

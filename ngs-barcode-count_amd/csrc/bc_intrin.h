@@ -19,6 +19,15 @@ typedef unsigned long long uint64_t;
 #endif
 #endif
 
+// Device tables are reached through explicit global-address-space pointers: a pointer rebuilt from an
+// integer (or loaded from memory) is otherwise "generic", and the compiler then emits FLAT loads,
+// which tie up the LDS counter as well as the vector-memory one.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BC_GLOBAL __attribute__((address_space(1)))
+#else
+#define BC_GLOBAL
+#endif
+
 namespace bc {
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -95,6 +104,11 @@ constexpr int kTT_Nor2ab = 0x03;    // ~(a | b)      (c ignored)
 // bytes that are zero -> 0x80 in that byte
 BC_HD uint32_t zero_bytes(uint32_t v) { return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; }
 // low `n` bits set, n in [0, 32]
+// the compiler folds the nested form into v_min3_u32
+BC_HD uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) {
+  const uint32_t m = a < b ? a : b;
+  return m < c ? m : c;
+}
 BC_HD uint32_t lowmask(uint32_t n) { return n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u); }
 
 }  // namespace bc

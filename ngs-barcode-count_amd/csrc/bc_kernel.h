@@ -5,9 +5,17 @@
 #pragma once
 #include "bc_lane.h"
 
+#ifdef BC_PROFILE
+// wall-clock breakdown of a wave's tile loop: clock ticks between consecutive marks, summed over all waves
+extern "C" __device__ unsigned long long bc_g_profile[16];
+#endif
+
 namespace bc {
 
-constexpr int kTPB = 256;          // reads (lanes) per workgroup
+#ifndef BC_TPB
+#define BC_TPB 256
+#endif
+constexpr int kTPB = BC_TPB;       // reads (lanes) per workgroup
 #ifndef BC_MIN_WAVES
 #define BC_MIN_WAVES 3  // occupancy floor (waves per SIMD) the register allocator must honour
 #endif
@@ -64,14 +72,14 @@ __device__ __forceinline__ void wave_seeded_min(const DevGroup& G, uint32_t q1, 
   const uint32_t nb = G.seed_nb, blen = G.seed_blen, bm = (1u << blen) - 1u;
   const uint32_t nbk = 1u << (2 * blen);
   const uint32_t lane = __lane_id();
-  const uint4* entries = reinterpret_cast<const uint4*>(G.seed_list());
+  const BC_GLOBAL uint4* entries = reinterpret_cast<const BC_GLOBAL uint4*>(G.seed_list());
   Nearest s;
   nearest_init(s);
   for (uint32_t b = 0; b < nb; ++b) {
     const uint32_t val = ((q1 >> (b * blen)) & bm) | (((q2 >> (b * blen)) & bm) << blen);
-    const uint32_t* off = G.seed_off() + (size_t)b * (nbk + 1);
+    const BC_GLOBAL uint32_t* off = G.seed_off() + (size_t)b * (nbk + 1);
     const uint32_t beg = off[val], end = off[val + 1];
-    const uint4* list = entries + (size_t)b * G.n_idx;
+    const BC_GLOBAL uint4* list = entries + (size_t)b * G.n_idx;
     // blocks before b on which a reference may not equal the capture (it was scored there)
     for (uint32_t i0 = beg; i0 < end; i0 += 256) {
       uint4 e[4];
@@ -247,6 +255,26 @@ __device__ __forceinline__ void wait_vm_keep(uint32_t keep) {
 }
 
 struct DeviceOps {
+#ifdef BC_PROFILE
+  unsigned long long t_last, acc[12];
+  __device__ __forceinline__ void mark(int k) {
+    __builtin_amdgcn_sched_barrier(0);  // keep each phase's instructions on its side of the mark
+    const unsigned long long now = __builtin_readcyclecounter();
+    __builtin_amdgcn_sched_barrier(0);
+    acc[k] += now - t_last;
+    t_last = now;
+  }
+#else
+  __device__ __forceinline__ void mark(int) const {}
+#endif
+  const Quad* area;       // the workgroup's LDS exact-match tables
+  bool with_tables;       // ... are loaded for this launch
+  __device__ __forceinline__ const Quad* lhash() const { return area; }
+#ifdef JIT_LHASH
+  __device__ __forceinline__ bool tables() const { return JIT_LHASH != 0; }  // fixed when the kernel was specialised
+#else
+  __device__ __forceinline__ bool tables() const { return with_tables; }
+#endif
   uint8_t* tile;          // this wave's LDS region for sequence lines
   uint8_t* qtile;         // ... for quality lines (pipelined fetch) -- equals `tile` when fetched on demand
   const uint8_t* qsrc;    // this tile's quality lines in global memory
@@ -258,16 +286,20 @@ struct DeviceOps {
 
   __device__ __forceinline__ bool any(bool c) const { return __any(c) != 0; }
   // the sequence bytes are dead once the planes are built: the next tile's sequence lines can land
+  bool late_fetch;  // experiment: request the next tile's sequence lines only after the gathers
   __device__ __forceinline__ void sequence_consumed() const {
     wave_lds_fence();
-    if (next_seq) dma_tile(tile, next_seq, 64u * (bytes_per_read()), lane);
+    if (next_seq && !late_fetch) dma_tile(tile, next_seq, 64u * (bytes_per_read()), lane);
+  }
+  __device__ __forceinline__ void groups_done() const {
+    if (next_seq && late_fetch) dma_tile(tile, next_seq, 64u * (bytes_per_read()), lane);
   }
   __device__ __forceinline__ uint32_t bytes_per_read() const { return stride_; }
   uint32_t stride_;
   __device__ __forceinline__ const uint32_t* stage_quality() const {
     if (qual_async) {
       // issued before this tile's sequence fetch of the next tile: everything but that fetch has landed
-      wait_vm_keep((next_seq ? chunks : 0u) + pending_add);
+      wait_vm_keep(((next_seq && !late_fetch) ? chunks : 0u) + pending_add);
       wave_lds_fence();
       return reinterpret_cast<const uint32_t*>(qtile);
     }
@@ -300,14 +332,17 @@ struct DeviceOps {
 // ------------------------------------------------------------------------------------------------
 // the hot kernel: SequenceParser::parse, 64 reads per wavefront, 4 wavefronts per workgroup
 // ------------------------------------------------------------------------------------------------
-template <int NW, int NWW>
+// kLens: per-read lengths are given.  A separate instantiation because the length load would
+// otherwise put a full vector-memory wait into every iteration, fetches in flight or not.
+template <int NW, int NWW, bool kLens>
 __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_t* __restrict__ seq,
                                                  const uint8_t* __restrict__ qual, const uint16_t* __restrict__ lens,
                                                  uint32_t stride, uint32_t read_len, uint32_t nd, uint64_t n_reads,
                                                  uint32_t region, uint32_t* __restrict__ table,
                                                  unsigned long long* __restrict__ slots, uint32_t* __restrict__ vals,
                                                  uint64_t smask, unsigned long long* __restrict__ counters,
-                                                 uint8_t* __restrict__ trace_outcome, uint64_t* __restrict__ trace_idx) {
+                                                 uint8_t* __restrict__ trace_outcome, uint64_t* __restrict__ trace_idx,
+                                                 uint32_t flags) {
   extern __shared__ uint4 smem[];
   __shared__ uint32_t s_cnt[kNCounters];
   const uint32_t tid = threadIdx.x;
@@ -316,16 +351,34 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
   if (tid < kNCounters) s_cnt[tid] = 0;
 
   const bool with_qual = pl.quality_on && !(pl.ablate & 0x8u);
+  // flags bit 0: software-pipelined tile fetch (two LDS regions per wave with the quality filter on);
+  // without it a wave has one region, filled on demand
+  // flags bit 1: the plan's exact-match tables are copied into LDS and used
+  const bool pipe = (flags & 1u) != 0u;
+#ifdef JIT_LHASH
+  const uint32_t lhash_vec = JIT_LHASH ? pl.lhash_vec : 0u;
+#else
+  const uint32_t lhash_vec = (flags & 2u) ? pl.lhash_vec : 0u;
+#endif
   DeviceOps ops;
-  // per wave: one region for sequence lines and, with the quality filter on, one for quality lines
-  ops.tile = reinterpret_cast<uint8_t*>(smem) + wave * region * (with_qual ? 2u : 1u);
-  ops.qtile = ops.tile + (with_qual ? region : 0u);
+  // LDS: [exact-match tables of the workgroup][per wave: sequence region (+ quality region)]
+  {
+    Quad* area = reinterpret_cast<Quad*>(smem);
+    const BC_GLOBAL Quad* image = reinterpret_cast<const BC_GLOBAL Quad*>(pl.lhash_image());
+    for (uint32_t i = tid; i < lhash_vec; i += kTPB) area[i] = image[i];
+    ops.area = area;
+    ops.with_tables = lhash_vec != 0u;
+  }
+  const uint32_t two = (with_qual && pipe) ? 2u : 1u;
+  ops.tile = reinterpret_cast<uint8_t*>(smem) + lhash_vec * 16u + wave * region * two;
+  ops.qtile = ops.tile + (two == 2u ? region : 0u);
   ops.region = region;
   ops.lane = lane;
   ops.stride_ = stride;
   const uint32_t full_bytes = 64u * stride;
   ops.chunks = (full_bytes + 1023u) / 1024u;
   ops.pending_add = 0;
+  ops.late_fetch = (pl.ablate & 0x400u) != 0u;
 
   // Persistent wavefronts: wave-tile t = 64 consecutive reads; this wave takes tiles
   // gid, gid + G, gid + 2G, ...  No workgroup barrier inside the loop; the outcome counters stay in
@@ -346,7 +399,7 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
   }
   uint64_t t = (uint64_t)blockIdx.x * (kTPB / 64) + wave;
   bool seq_ready = false, qual_ready = false;  // requested ahead of time
-  if (t < n_full && !(pl.ablate & 0x80u)) {
+  if (t < n_full && pipe) {
     dma_tile(ops.tile, seq + (t << 6) * stride, full_bytes, lane);
     seq_ready = true;
     if (with_qual) {
@@ -354,12 +407,17 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
       qual_ready = true;
     }
   }
+  __syncthreads();  // exact-match tables in place, s_cnt zeroed
+#ifdef BC_PROFILE
+  for (int k = 0; k < 12; ++k) ops.acc[k] = 0;
+  ops.t_last = __builtin_readcyclecounter();
+#endif
   for (; t < n_tiles; t += n_waves) {
     const uint64_t wfirst = t << 6;
     const uint32_t n_w = n_reads - wfirst < 64u ? (uint32_t)(n_reads - wfirst) : 64u;
     const uint64_t goff = wfirst * stride;  // multiple of 64 bytes: 16-byte aligned
     const uint64_t tn = t + n_waves;
-    const bool next_full = tn < n_full && !(pl.ablate & 0x80u);
+    const bool next_full = tn < n_full && pipe;
     ops.qsrc = qual + goff;
     ops.bytes = n_w * stride;
     ops.next_seq = next_full ? seq + (tn << 6) * stride : nullptr;
@@ -371,17 +429,19 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
       wave_lds_fence();
     } else {
       wave_lds_fence();  // the previous tile's last LDS reads are done before the tile is overwritten
-      if (!(pl.ablate & 0x80u)) stage_tile(ops.tile, seq + goff, ops.bytes, full_bytes, (uint8_t)'A', lane);
+      stage_tile(ops.tile, seq + goff, ops.bytes, full_bytes, (uint8_t)'A', lane);
       wave_lds_fence();
     }
 
+    ops.mark(1);
     const bool active = lane < n_w;
     uint32_t len = 0;
-    if (active) len = lens ? (uint32_t)lens[wfirst + lane] : read_len;
+    if (active) len = kLens ? (uint32_t)lens[wfirst + lane] : read_len;
     const uint32_t base = (active ? lane : 0u) * stride;
     const ReadResult r =
         process_read<DeviceOps, NW, NWW>(pl, ops, reinterpret_cast<const uint32_t*>(ops.tile), base, len, nd, active);
 
+    ops.mark(8);
     uint32_t outcome = r.outcome;
     if (pl.has_random) {
       // Results::add_count with a random barcode (info.rs:770-802): insert (tuple, random) into the
@@ -425,9 +485,13 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
         ops.pending_add = pl.sparse ? 0u : 1u;  // map_slot's compare-and-swap is waited for; the add is not
       }
     }
+    ops.mark(9);
   }
+#ifdef BC_PROFILE
+  if (lane == 0)
+    for (int k = 0; k < 12; ++k) atomicAdd(&bc_g_profile[k], ops.acc[k]);
+#endif
 
-  __syncthreads();  // s_cnt zeroed
   if (lane == 0) {
 #pragma unroll
     for (uint32_t k = 0; k < kNCounters; ++k)

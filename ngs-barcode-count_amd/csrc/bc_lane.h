@@ -539,14 +539,19 @@ BC_HD uint32_t dtable_entry(const DevGroup& G, uint32_t q) {
 // the capture with N replaced by r's base there.  Hence the nearest references of the capture are
 // the nearest references of its four substitutions at the smallest of their four minimum
 // distances D; the match is unique iff exactly one substitution reaches D and does so uniquely.
-BC_HD uint32_t single_n_lookup(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t qn) {
+// (table, len, max_err may differ from lane to lane)
+BC_HD uint32_t single_n_lookup(const BC_GLOBAL uint32_t* table, uint32_t len, uint32_t max_err, uint32_t q1, uint32_t q2,
+                               uint32_t qn) {
   const uint32_t k = ctz(qn);
   const uint32_t b1 = q1 & ~qn, b2 = q2 & ~qn;
   uint32_t best = 256u, res = kFail;
   bool ok = false;
+  uint32_t tt[4];
+#pragma unroll
+  for (uint32_t b = 0; b < 4; ++b) tt[b] = table[(b1 | ((b & 1u) << k)) | ((b2 | ((b >> 1) << k)) << len)];
 #pragma unroll
   for (uint32_t b = 0; b < 4; ++b) {
-    const uint32_t t = G.dtable()[(b1 | ((b & 1u) << k)) | ((b2 | ((b >> 1) << k)) << G.len)];
+    const uint32_t t = tt[b];
     const uint32_t d = (t >> 16) & 0xFFu;
     if (d < best) {
       best = d;
@@ -556,7 +561,48 @@ BC_HD uint32_t single_n_lookup(const DevGroup& G, uint32_t q1, uint32_t q2, uint
       ok = false;
     }
   }
-  return (ok && best <= G.max_err && res != (uint32_t)kFail16) ? res : kFail;
+  return (ok && best <= max_err && res != (uint32_t)kFail16) ? res : kFail;
+}
+
+// LDS exact-match table in front of dtable (bc_device_plan.h): the reference index of a capture
+// that is a stored reference, kFail for everything else
+struct alignas(16) Quad {
+  uint32_t x, y, z, w;
+};
+// `off`, `shift`, `len` may differ from lane to lane
+BC_HD uint32_t lhash_probe(const Quad* __restrict__ area, uint32_t off, uint32_t shift, uint32_t len, uint32_t key) {
+  const uint32_t ibits = 32u - 2u * len;
+  const Quad e = area[off + ((key * kLhashMul1) >> shift)];
+  const Quad f = area[off + ((key * kLhashMul2) >> shift)];
+  const uint32_t kk = key << ibits;
+  // an entry of this key leaves only its index after the xor; every other entry keeps a high bit
+  const uint32_t m = min3u(min3u(e.x ^ kk, e.y ^ kk, e.z ^ kk), min3u(e.w ^ kk, f.x ^ kk, f.y ^ kk),
+                           min3u(f.z ^ kk, f.w ^ kk, 0xFFFFFFFFu));
+  return (m >> ibits) == 0u ? m : kFail;
+}
+BC_HD uint32_t lhash_lookup(const Quad* __restrict__ area, const DevGroup& G, uint32_t key) {
+  return lhash_probe(area, G.lhash_off, G.lhash_shift, G.len, key);
+}
+
+// A capture with one 'N' against a complete LDS table: the reference it stands for when exactly one
+// of its four substitutions is a reference (distance 0, unique); kFail with settled = true when two
+// or more are (a tie at distance 0) or when no mismatch is allowed; otherwise settled = false -- the
+// nearest references are one or more mismatches away and dtable has to be asked (single_n_lookup).
+BC_HD uint32_t single_n_lhash(const Quad* __restrict__ area, uint32_t off, uint32_t shift, uint32_t len, uint32_t max_err,
+                              uint32_t q1, uint32_t q2, uint32_t qn, bool& settled) {
+  const uint32_t k = ctz(qn);
+  const uint32_t b1 = q1 & ~qn, b2 = q2 & ~qn;
+  uint32_t hits = 0, res = kFail;
+#pragma unroll
+  for (uint32_t b = 0; b < 4; ++b) {
+    const uint32_t t = lhash_probe(area, off, shift, len, (b1 | ((b & 1u) << k)) | ((b2 | ((b >> 1) << k)) << len));
+    if (t != kFail) {
+      ++hits;
+      res = t;
+    }
+  }
+  settled = hits != 0u || max_err == 0u;
+  return hits == 1u ? res : kFail;
 }
 
 // ---- the per-read decision tree ---------------------------------------------------------------
@@ -571,6 +617,9 @@ struct ReadResult {
 //   uint32_t nearest(const DevGroup&, q1,q2,qn,qx, bool need) -- cooperative Hamming search, every lane calls it
 //   void sequence_consumed()                     -- called once, by every lane, after the last read of the
 //                                                   sequence bytes (the GPU starts fetching the next tile)
+//   void mark(int)                               -- profiling hook (no-op outside BC_PROFILE builds)
+//   const Quad* lhash(), bool tables()           -- the LDS exact-match area (plan.lhash_vec uint4s), and whether
+//                                                   it is loaded
 //   const uint32_t* stage_quality()              -- called once, by every lane, when the quality filter is
 //                                                   on: returns where the quality lines are
 // NW = 32-base words per read; NWW = words of candidate offsets / repair windows (len - L + 1 <= 32*NWW)
@@ -603,6 +652,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
     for (int w = 0; w < NW; ++w) h |= hi[w] & inr[w];
     unsupported = h != 0u;  // non-ASCII: the reference's char positions no longer equal byte positions
   }
+  ops.mark(2);
   ops.sequence_consumed();
 #pragma unroll
   for (int w = 0; w < NW; ++w) {
@@ -632,10 +682,12 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
 
   uint32_t outcome = kMatched;
   if (!found) outcome = kConstantRegion;  // parse.rs:145
+  ops.mark(3);
 
   // ---- quality filter (parse.rs:98-119, 331-375) ------------------------------------------------
   if (pl.quality_on && !(pl.ablate & 0x8u)) {
     const uint32_t* qual32 = ops.stage_quality();
+    ops.mark(4);
     // after a repair the quality line is read from offset 0
     const uint32_t qstart = repaired ? 0u : start;
     const uint32_t avail = len - qstart;  // quality line assumed as long as the sequence line
@@ -650,6 +702,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
     }
     if (outcome == kMatched && low) outcome = kLowQuality;  // parse.rs:111
   }
+  ops.mark(5);
 
   // ---- barcodes: SequenceMatchResult::new (parse.rs:439-524) -----------------------------------
   // bring the construct to bit 0 so that every capture sits at a wave-uniform position
@@ -665,11 +718,14 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
   // verdicts are consumed in order -- the gathers of one read overlap instead of queueing up
   for (uint32_t g0 = 0; g0 < ng; g0 += 4) {
     uint32_t q1[4], q2[4], qn[4], qx[4], r[4];
-    bool need[4];
+    bool need[4], gather[4], gather_n[4];
+    uint32_t pend_n = 0;  // groups (bit u) whose capture holds exactly one 'N' and has a complete LDS table
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       r[u] = kFail;
       need[u] = false;
+      gather[u] = false;
+      gather_n[u] = false;
       q1[u] = q2[u] = qn[u] = qx[u] = 0;
       if (g0 + u < ng) {  // wave-uniform
         const DevGroup& G = pl.groups[g0 + u];
@@ -679,11 +735,17 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
           const bool clean = (qn[u] | qx[u]) == 0u;
           if (pre_ok) {
             if (G.mode == kSetDirect) {
+              const bool use_lds = G.lhash_shift && ops.tables();
               if (clean) {
-                const uint32_t t = G.dtable()[q1[u] | (q2[u] << G.len)] & 0xFFFFu;
-                r[u] = t == (uint32_t)kFail16 ? kFail : t;
+                // a capture that is a reference is answered from LDS; the others go to the table, unless
+                // no mismatch is allowed: then "not a reference" is already the verdict
+                if (use_lds) r[u] = lhash_lookup(ops.lhash(), G, q1[u] | (q2[u] << G.len));
+                gather[u] = r[u] == kFail && !(use_lds && G.lhash_complete && G.max_err == 0u);
               } else if (qx[u] == 0u && !G.has_odd && (qn[u] & (qn[u] - 1u)) == 0u && !(pl.ablate & 0x100u)) {
-                r[u] = single_n_lookup(G, q1[u], q2[u], qn[u]);
+                if (use_lds && G.lhash_complete)
+                  pend_n |= 1u << u;  // settled in LDS below, all groups in one pass
+                else
+                  gather_n[u] = true;
               } else {
                 need[u] = true;
               }
@@ -710,6 +772,82 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
         }
       }
     }
+    // Captures with one 'N' are rare per lane but not per wavefront: every lane settles its lowest
+    // pending group, so one pass usually serves the whole wave whichever groups the 'N's fell into.
+    while (ops.any(pend_n != 0u)) {
+      const uint32_t u_sel = pend_n ? ctz(pend_n) : 0u;
+      uint32_t s_q1 = 0, s_q2 = 0, s_qn = 1u, s_off = 0, s_shift = 31u, s_len = 1u, s_max = 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (g0 + u < ng) {
+          const DevGroup& G = pl.groups[g0 + u];
+          const bool me = u_sel == (uint32_t)u;
+          s_q1 = me ? q1[u] : s_q1;
+          s_q2 = me ? q2[u] : s_q2;
+          s_qn = me ? qn[u] : s_qn;
+          s_off = me ? G.lhash_off : s_off;
+          s_shift = me ? G.lhash_shift : s_shift;
+          s_len = me ? G.len : s_len;
+          s_max = me ? G.max_err : s_max;
+        }
+      }
+      bool settled = true;
+      uint32_t rs = kFail;
+      if (pend_n) rs = single_n_lhash(ops.lhash(), s_off, s_shift, s_len, s_max, s_q1, s_q2, s_qn, settled);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool me = pend_n != 0u && u_sel == (uint32_t)u;
+        r[u] = me ? rs : r[u];
+        gather_n[u] = me ? !settled : gather_n[u];
+      }
+      pend_n &= pend_n - 1u;
+    }
+    // correction-table gathers of the captures LDS did not answer: all lanes load (the idle ones entry
+    // 0, one shared cache line), so the four loads are in flight together
+    uint32_t tv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      tv[u] = 0;
+      if (g0 + u < ng && pl.groups[g0 + u].mode == kSetDirect && ops.any(gather[u])) {
+        const DevGroup& G = pl.groups[g0 + u];
+        tv[u] = G.dtable()[gather[u] ? (q1[u] | (q2[u] << G.len)) : 0u];
+      }
+    }
+    ops.mark(6);
+    // one 'N' and no substitution is a reference (or no LDS table): four table entries decide.  As
+    // above, every lane takes its lowest pending group, so the wave usually needs one round trip --
+    // and the gathers issued above are still in flight, so it is the only one.
+    {
+      uint32_t pend_g = 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) pend_g |= gather_n[u] ? (1u << u) : 0u;
+      while (ops.any(pend_g != 0u)) {
+        const uint32_t u_sel = pend_g ? ctz(pend_g) : 0u;
+        uint32_t s_q1 = 0, s_q2 = 0, s_qn = 1u, s_len = 1u, s_max = 0;
+        uint64_t s_tab = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (g0 + u < ng && pl.groups[g0 + u].mode == kSetDirect) {
+            const DevGroup& G = pl.groups[g0 + u];
+            const bool me = u_sel == (uint32_t)u;
+            s_q1 = me ? q1[u] : s_q1;
+            s_q2 = me ? q2[u] : s_q2;
+            s_qn = me ? qn[u] : s_qn;
+            s_len = me ? G.len : s_len;
+            s_max = me ? G.max_err : s_max;
+            s_tab = me ? (uint64_t)G.dtable() : s_tab;
+          }
+        }
+        uint32_t rs = kFail;
+        if (pend_g) rs = single_n_lookup(reinterpret_cast<const BC_GLOBAL uint32_t*>(s_tab), s_len, s_max, s_q1, s_q2, s_qn);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = (pend_g != 0u && u_sel == (uint32_t)u) ? rs : r[u];
+        pend_g &= pend_g - 1u;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (gather[u]) r[u] = (tv[u] & 0xFFFFu) == (uint32_t)kFail16 ? kFail : (tv[u] & 0xFFFFu);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (g0 + u < ng) {
@@ -734,6 +872,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
       }
     }
   }
+  ops.groups_done();
   // ---- random barcode: kept as captured, never corrected (parse.rs:510-516) ------------------
   if (pl.has_random) {
     uint32_t r1, r2, rn;

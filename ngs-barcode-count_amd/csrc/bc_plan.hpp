@@ -58,6 +58,7 @@ struct HostSet {
 struct HostDevPlan {
   DevPlan plan;                // device pointers still null
   std::vector<HostSet> sets;   // one per plan.groups entry
+  std::vector<uint32_t> lhash; // image of the LDS exact-match area (plan.lhash_vec uint4s)
   uint64_t table_entries = 0;
   uint32_t n_samples = 1;
 };

@@ -16,8 +16,13 @@ namespace {
 
 struct HostOps {
   const uint32_t* qual32 = nullptr;
+  const bc::Quad* area = nullptr;
+  const bc::Quad* lhash() const { return area; }
+  bool tables() const { return area != nullptr; }
   const uint32_t* stage_quality() const { return qual32; }
   void sequence_consumed() const {}
+  void mark(int) const {}
+  void groups_done() const {}
   bool any(bool c) const { return c; }
   uint32_t nearest(const bc::DevGroup& G, uint32_t q1, uint32_t q2, uint32_t qn, uint32_t qx, bool need) const {
     if (!need) return bc::kFail;
@@ -35,6 +40,7 @@ struct HostOps {
 struct EmuPlan {
   bc::HostDevPlan h;
   std::vector<std::vector<uint32_t>> dtables;
+  std::vector<bc::Quad> lhash;  // 16-byte aligned copy of h.lhash
 };
 
 template <int NW, int NWW>
@@ -53,6 +59,7 @@ void run(const EmuPlan& E, const uint8_t* seq, const uint8_t* qual, const uint16
     if (qual) memcpy((uint8_t*)q32.data() + base, qual + i * stride, stride);
     const uint32_t len = lens ? lens[i] : read_len;
     ops.qual32 = q32.data();
+    ops.area = reinterpret_cast<const bc::Quad*>(E.lhash.data());
     bc::ReadResult r = bc::process_read<HostOps, NW, NWW>(E.h.plan, ops, s32.data(), base, len, nd, true);
     outcomes[i] = (uint8_t)r.outcome;
     idx[i] = r.dense_idx;
@@ -71,6 +78,8 @@ void* emu_plan_create(const bc_plan* p) {
     return nullptr;
   }
   E->dtables.resize(E->h.plan.n_groups);
+  E->lhash.resize(E->h.plan.lhash_vec);
+  if (!E->lhash.empty()) memcpy(E->lhash.data(), E->h.lhash.data(), E->h.lhash.size() * 4);
   HostOps ops;
   for (uint32_t g = 0; g < E->h.plan.n_groups; ++g) {
     bc::DevGroup& G = E->h.plan.groups[g];

@@ -64,9 +64,28 @@ def test_fix_error_kat_on_device(k):
     assert pkg.fix_error(k["query"], k["set"][::-1], k["max"]) == k["expect"]
 
 
+@pytest.fixture
+def kernel(request, monkeypatch, tmp_path_factory):
+    """generic: the kernel that reads the plan from memory; specialised: the one compiled for the plan's
+    scheme (forced here -- by default it only serves batches of 2^20 reads or more)"""
+    monkeypatch.setenv("BC_JIT", "force" if request.param == "specialised" else "0")
+    monkeypatch.setenv("BC_JIT_CACHE", str(tmp_path_factory.getbasetemp() / "jit_cache"))
+    return request.param
+
+
+def check_kernel(eng, kernel):
+    name = eng.kernel_name()
+    nw, nww = (int(v) for v in name[name.index("<") + 1:-1].split(","))
+    if kernel == "specialised" and nw == 4 and nww <= 2:
+        assert name.startswith("bc_jit_match_count"), name
+    else:
+        assert name.startswith("match_count_kernel"), name
+
+
 @pytest.mark.parametrize("name", NO_RANDOM)
 @pytest.mark.parametrize("use_lens", [False, True])
-def test_engine_vs_oracle(name, use_lens):
+@pytest.mark.parametrize("kernel", ["generic", "specialised"], indirect=True)
+def test_engine_vs_oracle(name, use_lens, kernel):
     c = cases.build_case(name, seed=11 + use_lens, n=3000)
     if not use_lens:
         rl = min(len(s) for s, _ in c["reads"])
@@ -82,11 +101,13 @@ def test_engine_vs_oracle(name, use_lens):
         assert got[k] == v, (k, got, o.counters)
     assert got["total_reads"] == len(c["reads"]) and got["unsupported_reads"] == 0
     assert eng.result_rows() == o.rows()
+    check_kernel(eng, kernel)
     eng.close()
 
 
 @pytest.mark.parametrize("name", cases.RANDOM_ENGINE_CASES)
-def test_random_barcode_engine_vs_oracle(name):
+@pytest.mark.parametrize("kernel", ["generic", "specialised"], indirect=True)
+def test_random_barcode_engine_vs_oracle(name, kernel):
     """PCR-duplicate collapse on the device hash set (info.rs:770-802).  Which copy of a duplicated
     molecule is the "matched" one depends on scheduling, so per read matched/duplicate are one
     class; the counters and the (sample, tuple, distinct count) rows are compared exactly."""
@@ -105,6 +126,7 @@ def test_random_barcode_engine_vs_oracle(name):
         assert got[k] == v, (k, got, o.counters)
     assert eng.key_count() == o.counters["matched"]
     assert eng.result_rows() == o.rows()
+    check_kernel(eng, kernel)
     # the same reads again: every one of them is now a duplicate
     eng2, _, _ = run_device(plan, np.concatenate([seq, seq]), np.concatenate([qual, qual]),
                             np.concatenate([lens, lens]), stride, stride)

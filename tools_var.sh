@@ -1,0 +1,17 @@
+#!/bin/bash
+mkdir -p gpurun_out
+export BC_JIT_CACHE=$PWD/gpurun_out/jitc
+run() { # label, config, reads, env...
+  local label=$1 cfg=$2 n=$3; shift 3
+  env "$@" timeout -k 10 200 python bench.py --config $cfg --reads $n --steps 5 --warmup 2 --no-cpu 2>gpurun_out/err.txt | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('$cfg $label', 'kernel_ms %.3f' % d['roofline']['kernel_avg_ms'], 'Greads/s %.2f' % (d['roofline']['kernel_reads_per_s']/1e9), 'value %.3g' % d['value'])
+" | tee -a gpurun_out/var.txt
+  grep -i "barcode-count" gpurun_out/err.txt | head -3
+}
+for i in 1 2 3; do
+  run "prev" config3 20000000 BC_LIB=$PWD/build_variants/libprev.so BC_JIT=0
+  run "jit lhash=1" config3 20000000 BC_JIT=force BC_LHASH=1
+  run "jit lhash=0" config3 20000000 BC_JIT=force BC_LHASH=0
+done
+rocm-smi --showclocks 2>/dev/null | head -20
