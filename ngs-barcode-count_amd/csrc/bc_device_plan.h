@@ -29,8 +29,8 @@ constexpr int kClasses = 5;       // A, C, T, G constants + scheme-N ([AGCT]) po
 constexpr int kMaxNW = 10;        // 32-base words per read: reads up to 320 bases
 constexpr uint32_t kFail = 0xFFFFFFFFu;
 constexpr uint16_t kFail16 = 0xFFFFu;
-constexpr uint32_t kLhashMul1 = 0x9E3779B1u;
-constexpr uint32_t kLhashMul2 = 0x85EBCA6Bu;
+constexpr uint32_t kLhashMul1 = 0x9E3779u;  // 24-bit multipliers: keys are below 2^20 (len <= 10), so the
+constexpr uint32_t kLhashMul2 = 0x85EBCBu;  // product fits the full-rate 24-bit multiply
 constexpr uint32_t kLhashMaxVec = 2048;  // 32 KiB of LDS per workgroup at most
 
 // letter code of an ASCII base: (c >> 1) & 3  ->  A=0 C=1 T=2 G=3

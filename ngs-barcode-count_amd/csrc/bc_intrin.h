@@ -104,6 +104,9 @@ constexpr int kTT_Nor2ab = 0x03;    // ~(a | b)      (c ignored)
 // bytes that are zero -> 0x80 in that byte
 BC_HD uint32_t zero_bytes(uint32_t v) { return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; }
 // low `n` bits set, n in [0, 32]
+// low 32 bits of a 24-bit x 24-bit product: v_mul_u32_u24, full rate (v_mul_lo_u32 is quarter rate)
+// (the masks let the compiler prove the operand widths and pick that instruction)
+BC_HD uint32_t mul24(uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
 // the compiler folds the nested form into v_min3_u32
 BC_HD uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) {
   const uint32_t m = a < b ? a : b;

@@ -572,8 +572,8 @@ struct alignas(16) Quad {
 // `off`, `shift`, `len` may differ from lane to lane
 BC_HD uint32_t lhash_probe(const Quad* __restrict__ area, uint32_t off, uint32_t shift, uint32_t len, uint32_t key) {
   const uint32_t ibits = 32u - 2u * len;
-  const Quad e = area[off + ((key * kLhashMul1) >> shift)];
-  const Quad f = area[off + ((key * kLhashMul2) >> shift)];
+  const Quad e = area[off + (mul24(key, kLhashMul1) >> shift)];
+  const Quad f = area[off + (mul24(key, kLhashMul2) >> shift)];
   const uint32_t kk = key << ibits;
   // an entry of this key leaves only its index after the xor; every other entry keeps a high bit
   const uint32_t m = min3u(min3u(e.x ^ kk, e.y ^ kk, e.z ^ kk), min3u(e.w ^ kk, f.x ^ kk, f.y ^ kk),
@@ -718,14 +718,14 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
   // verdicts are consumed in order -- the gathers of one read overlap instead of queueing up
   for (uint32_t g0 = 0; g0 < ng; g0 += 4) {
     uint32_t q1[4], q2[4], qn[4], qx[4], r[4];
-    bool need[4], gather[4], gather_n[4];
+    // per-lane flags of the four groups, one bit each.  Packed words (vector registers) rather than
+    // bools: a bool that lives across the phase is a wave-wide mask in two scalar registers, and the
+    // kernel is short of those.
+    uint32_t need_m = 0, gather_m = 0, gather_n_m = 0;
     uint32_t pend_n = 0;  // groups (bit u) whose capture holds exactly one 'N' and has a complete LDS table
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       r[u] = kFail;
-      need[u] = false;
-      gather[u] = false;
-      gather_n[u] = false;
       q1[u] = q2[u] = qn[u] = qx[u] = 0;
       if (g0 + u < ng) {  // wave-uniform
         const DevGroup& G = pl.groups[g0 + u];
@@ -740,17 +740,17 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
                 // a capture that is a reference is answered from LDS; the others go to the table, unless
                 // no mismatch is allowed: then "not a reference" is already the verdict
                 if (use_lds) r[u] = lhash_lookup(ops.lhash(), G, q1[u] | (q2[u] << G.len));
-                gather[u] = r[u] == kFail && !(use_lds && G.lhash_complete && G.max_err == 0u);
+                gather_m |= (r[u] == kFail && !(use_lds && G.lhash_complete && G.max_err == 0u)) ? (1u << u) : 0u;
               } else if (qx[u] == 0u && !G.has_odd && (qn[u] & (qn[u] - 1u)) == 0u && !(pl.ablate & 0x100u)) {
                 if (use_lds && G.lhash_complete)
                   pend_n |= 1u << u;  // settled in LDS below, all groups in one pass
                 else
-                  gather_n[u] = true;
+                  gather_n_m |= 1u << u;
               } else {
-                need[u] = true;
+                need_m |= 1u << u;
               }
             } else if (G.mode == kSetHash) {
-              need[u] = true;
+              need_m |= 1u << u;
               if (clean) {
                 const uint64_t key = (uint64_t)q1[u] | ((uint64_t)q2[u] << 32);
                 uint32_t h = (uint32_t)hash64(key) & G.hmask;
@@ -759,14 +759,14 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
                   if (v == kFail) break;
                   if (G.hkeys()[h] == key) {
                     r[u] = v;
-                    need[u] = false;
+                    need_m &= ~(1u << u);
                     break;
                   }
                   h = (h + 1u) & G.hmask;
                 }
               }
             } else {
-              need[u] = true;
+              need_m |= 1u << u;
             }
           }
         }
@@ -798,7 +798,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
       for (int u = 0; u < 4; ++u) {
         const bool me = pend_n != 0u && u_sel == (uint32_t)u;
         r[u] = me ? rs : r[u];
-        gather_n[u] = me ? !settled : gather_n[u];
+        gather_n_m |= (me && !settled) ? (1u << u) : 0u;
       }
       pend_n &= pend_n - 1u;
     }
@@ -808,9 +808,9 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       tv[u] = 0;
-      if (g0 + u < ng && pl.groups[g0 + u].mode == kSetDirect && ops.any(gather[u])) {
+      if (g0 + u < ng && pl.groups[g0 + u].mode == kSetDirect && ops.any((gather_m >> u) & 1u)) {
         const DevGroup& G = pl.groups[g0 + u];
-        tv[u] = G.dtable()[gather[u] ? (q1[u] | (q2[u] << G.len)) : 0u];
+        tv[u] = G.dtable()[((gather_m >> u) & 1u) ? (q1[u] | (q2[u] << G.len)) : 0u];
       }
     }
     ops.mark(6);
@@ -818,9 +818,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
     // above, every lane takes its lowest pending group, so the wave usually needs one round trip --
     // and the gathers issued above are still in flight, so it is the only one.
     {
-      uint32_t pend_g = 0;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) pend_g |= gather_n[u] ? (1u << u) : 0u;
+      uint32_t pend_g = gather_n_m;
       while (ops.any(pend_g != 0u)) {
         const uint32_t u_sel = pend_g ? ctz(pend_g) : 0u;
         uint32_t s_q1 = 0, s_q2 = 0, s_qn = 1u, s_len = 1u, s_max = 0;
@@ -847,14 +845,14 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (gather[u]) r[u] = (tv[u] & 0xFFFFu) == (uint32_t)kFail16 ? kFail : (tv[u] & 0xFFFFu);
+      if ((gather_m >> u) & 1u) r[u] = (tv[u] & 0xFFFFu) == (uint32_t)kFail16 ? kFail : (tv[u] & 0xFFFFu);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (g0 + u < ng) {
         const DevGroup& G = pl.groups[g0 + u];
         if (G.mode != kSetNone) {
           // a read that already failed an earlier group is not searched again (parse.rs:481, 500)
-          bool nd_ = need[u] && outcome == kMatched;
+          bool nd_ = ((need_m >> u) & 1u) && outcome == kMatched;
           if (pl.ablate & 0x2u) nd_ = false;
           const uint32_t rr = ops.nearest(G, q1[u], q2[u], qn[u], qx[u], nd_);
           if (nd_) r[u] = rr;

@@ -402,7 +402,7 @@ bool bc_plan::lower(HostDevPlan& out) const {
       bool placed = false;
       for (int moves = 0; moves < 500 && !placed; ++moves) {
         const uint32_t key = key_of(j);
-        const uint32_t b1 = (key * kLhashMul1) >> shift, b2 = (key * kLhashMul2) >> shift;
+        const uint32_t b1 = mul24(key, kLhashMul1) >> shift, b2 = mul24(key, kLhashMul2) >> shift;
         const uint32_t b = fill[b1] <= fill[b2] ? b1 : b2;
         if (fill[b] < 4) {
           slot_ref[(size_t)b * 4 + fill[b]++] = j;

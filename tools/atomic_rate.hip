@@ -1,0 +1,61 @@
+// Micro-benchmark behind DESIGN.md's counting section: throughput of no-return u32 atomic adds at random
+// addresses as a function of the table range they fall in (is a locality-restoring partition pass worth it?)
+//   hipcc --offload-arch=gfx950 -O3 -o tools/atomic_rate tools/atomic_rate.hip && tools/atomic_rate
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+__device__ __forceinline__ uint64_t mix(uint64_t x) {
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+  return x;
+}
+
+// every lane adds to `per` random counters inside [0, range)
+__global__ void scatter_add(uint32_t* table, uint64_t range, uint32_t per, uint64_t seed) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (uint32_t i = 0; i < per; ++i) {
+    const uint64_t h = mix(seed + t * per + i);
+    atomicAdd(&table[h % range], 1u);
+  }
+}
+
+// same address stream, plain loads (what a gather of that locality costs)
+__global__ void scatter_load(const uint32_t* table, uint64_t range, uint32_t per, uint64_t seed, uint32_t* sink) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t acc = 0;
+  for (uint32_t i = 0; i < per; ++i) acc += table[mix(seed + t * per + i) % range];
+  if (acc == 0xFFFFFFFFu) sink[0] = acc;
+}
+
+int main() {
+  const uint64_t max_entries = 4ull << 30;  // 16 GiB of u32
+  uint32_t* table = nullptr;
+  if (hipMalloc((void**)&table, max_entries * 4) != hipSuccess) { printf("alloc failed\n"); return 1; }
+  hipMemset(table, 0, max_entries * 4);
+  uint32_t* sink = nullptr;
+  hipMalloc((void**)&sink, 4);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  const uint32_t per = 16, threads = 256, blocks = 256 * 64;  // 67 M operations per launch
+  const double n = (double)per * threads * blocks;
+  const uint64_t ranges[] = {1ull << 20, 1ull << 22, 1ull << 24, 1ull << 26, 1ull << 28, 1ull << 30, 4ull << 30};
+  for (uint64_t r : ranges) {
+    float ms_a = 0, ms_l = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+      hipEventRecord(e0);
+      hipLaunchKernelGGL(scatter_add, dim3(blocks), dim3(threads), 0, 0, table, r, per, 12345ull + rep);
+      hipEventRecord(e1);
+      hipEventSynchronize(e1);
+      hipEventElapsedTime(&ms_a, e0, e1);
+      hipEventRecord(e0);
+      hipLaunchKernelGGL(scatter_load, dim3(blocks), dim3(threads), 0, 0, table, r, per, 12345ull + rep, sink);
+      hipEventRecord(e1);
+      hipEventSynchronize(e1);
+      hipEventElapsedTime(&ms_l, e0, e1);
+    }
+    printf("range %8.0f MiB  atomics %7.2f G/s   loads %7.2f G/s\n", r * 4.0 / (1 << 20), n / ms_a / 1e6, n / ms_l / 1e6);
+    fflush(stdout);
+  }
+  return 0;
+}
