@@ -163,7 +163,7 @@ def main():
     achieved = (b_alg * n) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
 
     # HBM bytes per launch from the PMC counters (FETCH_SIZE doubled per the gfx950 correction,
-    # + WRITE_SIZE), measured by tools_profile.sh in separate rocprofv3 passes of this very workload
+    # + WRITE_SIZE), measured by tools/scripts/tools_profile.sh in separate rocprofv3 passes of this very workload
     # and committed under profiles/; null when no summary of this workload size exists
     traffic, traffic_src = None, None
     try:

@@ -2,7 +2,7 @@
 """perf-debug / DESIGN.md numbers: (1) PCIe-inclusive rate of bc_engine_submit_host, (2) end-to-end
 rate of the barcode-count command line on a synthetic FASTQ file (ingest + GPU + writers)."""
 import os, subprocess, sys, time
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import ngs_barcode_count_amd as pkg
