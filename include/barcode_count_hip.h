@@ -163,6 +163,12 @@ int bc_engine_key_count(bc_engine *e, uint64_t *n);
 int bc_engine_export_keys(bc_engine *e, void *d_keys, uint64_t capacity, uint64_t *n);
 int bc_engine_import_keys(bc_engine *e, const void *d_keys, uint64_t n, uint64_t *n_new);
 int bc_engine_clear_keys(bc_engine *e);
+/* Plans that keep raw captures and have NO random barcode count in a (key -> count) map.  Across GPUs
+ * the maps are merged by sending every (key, count) pair to the key's owner (or all of them to the
+ * root), where bc_engine_import_counts adds them in.  export with NULL buffers only counts the pairs.
+ * Device pointers: keys u64, counts u32. */
+int bc_engine_export_counts(bc_engine *e, void *d_keys, void *d_counts, uint64_t capacity, uint64_t *n);
+int bc_engine_import_counts(bc_engine *e, const void *d_keys, const void *d_counts, uint64_t n);
 
 /* Debug / parity-test hook: the next submits also write, for read i of the submit, its outcome
  * (BC_* counter index; BC_MATCHED = passed every test) to d_outcome_u8[i] and its dense table index

@@ -202,6 +202,15 @@ class Engine:
     def clear_keys(self):
         _check(self._lib, self._lib.bc_engine_clear_keys(self._e))
 
+    def export_counts(self, d_keys, d_counts, capacity):
+        """(key, count) pairs of a raw-key plan's map -> device buffers; None buffers: only their number"""
+        n = C.c_uint64()
+        _check(self._lib, self._lib.bc_engine_export_counts(self._e, d_keys, d_counts, capacity, C.byref(n)))
+        return n.value
+
+    def import_counts(self, d_keys, d_counts, n):
+        _check(self._lib, self._lib.bc_engine_import_counts(self._e, d_keys, d_counts, n))
+
     def timing(self, enable=True):
         _check(self._lib, self._lib.bc_engine_timing(self._e, 1 if enable else 0))
 

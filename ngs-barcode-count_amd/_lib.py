@@ -80,6 +80,8 @@ ENGINE_API = {
     "bc_engine_export_keys": (_int, [_vp, _vp, _u64, C.POINTER(C.c_uint64)]),
     "bc_engine_import_keys": (_int, [_vp, _vp, _u64, C.POINTER(C.c_uint64)]),
     "bc_engine_clear_keys": (_int, [_vp]),
+    "bc_engine_export_counts": (_int, [_vp, _vp, _vp, _u64, C.POINTER(_u64)]),
+    "bc_engine_import_counts": (_int, [_vp, _vp, _vp, _u64]),
     "bc_fix_error": (C.c_int64, [_cp, C.POINTER(_cp), _u64, C.c_uint16, _int]),
     "bc_fastq_count": (_int, [_vp, _cp, C.POINTER(C.c_uint64), _vp, _vp]),
     "bc_synth_create": (_vp, [_vp, C.POINTER(SynthParams)]),

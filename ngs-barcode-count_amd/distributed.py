@@ -38,33 +38,44 @@ def key_owner(keys, world):
     return ((h >> 33) & 0x7FFFFFFF) % world
 
 
-def exchange_keys(keys):
+def exchange_keys(keys, counts=None, dst=None):
     """all-to-all so that every key ends up on exactly one rank (duplicates across ranks meet on
-    their owner).  keys: int64 tensor of this rank's distinct keys -> int64 tensor received."""
+    their owner).  keys: int64 tensor of this rank's distinct keys -> int64 tensor received.
+    counts: optional int32 tensor travelling with the keys -> (keys, counts) received.
+    dst: send everything to that rank instead of spreading the keys by hash (the merge of raw-key
+    results, which the root needs whole to write them out)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     if world == 1:
-        return keys
-    owner = key_owner(keys, world)
+        return keys if counts is None else (keys, counts)
+    owner = key_owner(keys, world) if dst is None else torch.full_like(keys, dst)
     order = torch.argsort(owner)
     keys = keys[order].contiguous()
     send = torch.bincount(owner, minlength=world).to(torch.int64)
     recv = torch.empty_like(send)
     dist.all_to_all_single(recv, send)
-    out = torch.empty(int(recv.sum().item()), dtype=torch.int64, device=keys.device)
+    n_recv = int(recv.sum().item())
+    out = torch.empty(n_recv, dtype=torch.int64, device=keys.device)
     dist.all_to_all_single(out, keys, recv.tolist(), send.tolist())
-    return out
+    if counts is None:
+        return out
+    counts = counts[order].contiguous()
+    out_c = torch.empty(n_recv, dtype=counts.dtype, device=counts.device)
+    dist.all_to_all_single(out_c, counts, recv.tolist(), send.tolist())
+    return out, out_c
 
 
-def finish_random(engine, device, dst=0):
+def finish_random(engine, device, dst=0, gather=False):
     """Global PCR-duplicate collapse: export this rank's keys, exchange them, keep
     only the owned ones, fix the matched / duplicate counters, and leave per-tuple distinct counts
     in the engine's table for reduce_table() + bc_engine_finish on the root.  Returns the global
-    counters on rank dst."""
+    counters on rank dst.
+    gather=True (raw-key plans, whose results are a key map and not a table that could be summed):
+    every key goes to rank dst, whose engine then holds the whole set."""
     local = engine.counters()
     n = engine.key_count()
     keys = torch.empty(max(n, 1), dtype=torch.int64, device=device)
     engine.export_keys(keys.data_ptr(), n)
-    recv = exchange_keys(keys[:n])
+    recv = exchange_keys(keys[:n], dst=dst if gather else None)
     engine.clear_keys()
     owned = engine.import_keys(recv.data_ptr(), recv.numel()) if recv.numel() else 0
     fixed = dict(local)
@@ -73,3 +84,21 @@ def finish_random(engine, device, dst=0):
     fixed["matched"] = owned
     # (summed over ranks: matched = distinct keys overall, duplicates = all other passing reads)
     return reduce_counters(fixed, device, dst=dst)
+
+
+def finish_sparse(engine, device, dst=0):
+    """Raw-key plans (no sample / counted-barcode conversion file): counts live in a per-rank key map.
+    With a random barcode the (tuple, random) keys of every rank are gathered on rank dst (set union);
+    without one the (key, count) pairs are, and added up there.  Afterwards rank dst's engine holds the
+    job's result (bc_engine_finish / result rows); returns the global counters on rank dst."""
+    if engine.plan.random_barcode:
+        return finish_random(engine, device, dst=dst, gather=True)
+    n = engine.export_counts(None, None, 0)
+    keys = torch.empty(max(n, 1), dtype=torch.int64, device=device)
+    cnts = torch.empty(max(n, 1), dtype=torch.int32, device=device)
+    engine.export_counts(keys.data_ptr(), cnts.data_ptr(), n)
+    rk, rc = exchange_keys(keys[:n], cnts[:n], dst=dst)
+    engine.clear_keys()
+    if rk.numel():
+        engine.import_counts(rk.data_ptr(), rc.data_ptr(), rk.numel())
+    return reduce_counters(engine.counters(), device, dst=dst)

@@ -141,3 +141,51 @@ def test_two_ranks_random_barcode_key_exchange(tmp_path):
     out = str(tmp_path / "result.txt")
     mp.spawn(_worker_random, args=(2, _free_port(), out), nprocs=2, join=True)
     assert open(out).read() == "ok"
+
+
+def _worker_counts(rank, world, port, out_path):
+    """the merge of raw-key count maps: (key, count) pairs gathered on the root and added"""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import ngs_barcode_count_amd.distributed as bcdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(100 + rank)
+    # each rank saw some keys of a common universe, some of them on both ranks
+    universe = np.arange(1, 5001, dtype=np.int64) * 7919
+    mine = rng.choice(universe, size=3000, replace=False)
+    cnts = rng.integers(1, 50, size=mine.size).astype(np.int32)
+    for dst in (None, 0):
+        rk, rc = bcdist.exchange_keys(torch.from_numpy(mine), torch.from_numpy(cnts), dst=dst)
+        # what bc_engine_import_counts does on the device: add per key
+        got = {}
+        for k, c in zip(rk.tolist(), rc.tolist()):
+            got[k] = got.get(k, 0) + c
+        if dst is None:
+            assert all(int(bcdist.key_owner(torch.tensor([k]), world)[0]) == rank for k in list(got)[:200])
+        # everyone contributes its local truth; rank 0 checks the union
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (mine.tolist(), cnts.tolist(), got))
+        if rank == 0:
+            truth = {}
+            for m, c, _ in gathered:
+                for k, v in zip(m, c):
+                    truth[k] = truth.get(k, 0) + v
+            merged = {}
+            for _, _, g in gathered:
+                for k, v in g.items():
+                    assert k not in merged  # every key has exactly one holder after the exchange
+                    merged[k] = v
+            ok = merged == truth and (dst is None or len(gathered[1][2]) == 0)
+            with open(out_path, "a") as f:
+                f.write("ok;" if ok else "MISMATCH;")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_count_map_merge(tmp_path):
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_worker_counts, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert open(out).read() == "ok;ok;"

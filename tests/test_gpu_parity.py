@@ -138,6 +138,36 @@ def test_random_barcode_engine_vs_oracle(name, kernel):
     eng2.close()
 
 
+@pytest.mark.parametrize("name", ["raw_counted", "raw_sample"])
+def test_count_map_export_import_merges_shards(name):
+    """raw-key plans across GPUs: two engines count one half of the reads each; adding the second one's
+    (key, count) pairs into the first reproduces the single-engine result (bc_engine_export_counts /
+    bc_engine_import_counts, the primitives of distributed.finish_sparse)"""
+    import torch
+    c = cases.build_case(name, seed=31, n=3000)
+    plan = make_plan(c)
+    assert plan.mode == "sparse" and not plan.random_barcode
+    seq, qual, lens = readgen.to_arrays(c["reads"])
+    stride, half = seq.shape[1], seq.shape[0] // 2
+    a, _, _ = run_device(plan, seq[:half], qual[:half], lens[:half], stride, stride)
+    b, _, _ = run_device(plan, seq[half:], qual[half:], lens[half:], stride, stride)
+    n = b.export_counts(None, None, 0)
+    keys = torch.zeros(max(n, 1), dtype=torch.int64, device="cuda")
+    cnts = torch.zeros(max(n, 1), dtype=torch.int32, device="cuda")
+    assert b.export_counts(keys.data_ptr(), cnts.data_ptr(), n) == n
+    assert int(cnts[:n].sum()) == b.counters()["matched"]
+    a.import_counts(keys.data_ptr(), cnts.data_ptr(), n)
+    o = parity.oracle_for(c)
+    for sq, ql in c["reads"]:
+        o.process(sq, ql)
+    assert a.result_rows() == o.rows()
+    # clearing leaves an empty map
+    b.clear_keys()
+    assert b.export_counts(None, None, 0) == 0 and b.result_rows() == []
+    a.close()
+    b.close()
+
+
 def test_key_export_import_roundtrip():
     """the exchange primitives of the multi-GPU random-barcode path: export -> import into a fresh
     engine reproduces the set; importing twice adds nothing"""
