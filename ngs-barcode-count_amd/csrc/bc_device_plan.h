@@ -32,6 +32,12 @@ constexpr uint16_t kFail16 = 0xFFFFu;
 constexpr uint32_t kLhashMul1 = 0x9E3779u;  // 24-bit multipliers: keys are below 2^20 (len <= 10), so the
 constexpr uint32_t kLhashMul2 = 0x85EBCBu;  // product fits the full-rate 24-bit multiply
 constexpr uint32_t kLhashMaxVec = 2048;  // 32 KiB of LDS per workgroup at most
+// bucket of a key: 16 well-mixed bits of key * mul, scaled to [0, nb) -- nb need not be a power of two,
+// which lets a table be sized to its load instead of the next power of two (LDS is what limits
+// how many wavefronts stay resident).  Three full-rate 24-bit multiplies / shifts.
+BC_HD uint32_t lhash_bucket(uint32_t key, uint32_t mul, uint32_t nb) {
+  return mul24((mul24(key, mul) >> 8) & 0xFFFFu, nb) >> 16;
+}
 
 // letter code of an ASCII base: (c >> 1) & 3  ->  A=0 C=1 T=2 G=3
 enum { kCodeA = 0, kCodeC = 1, kCodeT = 2, kCodeG = 3, kClassFmtN = 4 };
@@ -84,7 +90,7 @@ struct DevGroup {
   // dtable gather (or, when no mismatch is allowed, fails right away).  Unused slots hold copies of
   // a real entry.  lhash_complete: every plain reference found a slot, so "not in the table" proves
   // "not a reference" (it always does unless the builder ran out of moves).
-  uint32_t lhash_shift;     // bucket = (key * kLhashMul{1,2}) >> lhash_shift; 0: no LDS table for this group
+  uint32_t lhash_nb;        // buckets of this group's table (lhash_bucket below); 0: no LDS table for this group
   uint32_t lhash_off;       // first bucket of this group in the workgroup's table area (16-byte units)
   uint32_t lhash_complete;
   uint32_t index;           // position in DevPlan::groups

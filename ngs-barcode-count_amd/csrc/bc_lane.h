@@ -570,10 +570,10 @@ struct alignas(16) Quad {
   uint32_t x, y, z, w;
 };
 // `off`, `shift`, `len` may differ from lane to lane
-BC_HD uint32_t lhash_probe(const Quad* __restrict__ area, uint32_t off, uint32_t shift, uint32_t len, uint32_t key) {
+BC_HD uint32_t lhash_probe(const Quad* __restrict__ area, uint32_t off, uint32_t nb, uint32_t len, uint32_t key) {
   const uint32_t ibits = 32u - 2u * len;
-  const Quad e = area[off + (mul24(key, kLhashMul1) >> shift)];
-  const Quad f = area[off + (mul24(key, kLhashMul2) >> shift)];
+  const Quad e = area[off + lhash_bucket(key, kLhashMul1, nb)];
+  const Quad f = area[off + lhash_bucket(key, kLhashMul2, nb)];
   const uint32_t kk = key << ibits;
   // an entry of this key leaves only its index after the xor; every other entry keeps a high bit
   const uint32_t m = min3u(min3u(e.x ^ kk, e.y ^ kk, e.z ^ kk), min3u(e.w ^ kk, f.x ^ kk, f.y ^ kk),
@@ -581,25 +581,36 @@ BC_HD uint32_t lhash_probe(const Quad* __restrict__ area, uint32_t off, uint32_t
   return (m >> ibits) == 0u ? m : kFail;
 }
 BC_HD uint32_t lhash_lookup(const Quad* __restrict__ area, const DevGroup& G, uint32_t key) {
-  return lhash_probe(area, G.lhash_off, G.lhash_shift, G.len, key);
+  return lhash_probe(area, G.lhash_off, G.lhash_nb, G.len, key);
 }
 
 // A capture with one 'N' against a complete LDS table: the reference it stands for when exactly one
 // of its four substitutions is a reference (distance 0, unique); kFail with settled = true when two
 // or more are (a tie at distance 0) or when no mismatch is allowed; otherwise settled = false -- the
 // nearest references are one or more mismatches away and dtable has to be asked (single_n_lookup).
-BC_HD uint32_t single_n_lhash(const Quad* __restrict__ area, uint32_t off, uint32_t shift, uint32_t len, uint32_t max_err,
+BC_HD uint32_t single_n_lhash(const Quad* __restrict__ area, uint32_t off, uint32_t nb, uint32_t len, uint32_t max_err,
                               uint32_t q1, uint32_t q2, uint32_t qn, bool& settled) {
   const uint32_t k = ctz(qn);
   const uint32_t b1 = q1 & ~qn, b2 = q2 & ~qn;
+  const uint32_t ibits = 32u - 2u * len;
+  // all eight bucket reads are issued before the first is looked at: one LDS round trip
+  uint32_t key[4];
+  Quad e[4], f[4];
+#pragma unroll
+  for (uint32_t b = 0; b < 4; ++b) {
+    key[b] = (b1 | ((b & 1u) << k)) | ((b2 | ((b >> 1) << k)) << len);
+    e[b] = area[off + lhash_bucket(key[b], kLhashMul1, nb)];
+    f[b] = area[off + lhash_bucket(key[b], kLhashMul2, nb)];
+  }
   uint32_t hits = 0, res = kFail;
 #pragma unroll
   for (uint32_t b = 0; b < 4; ++b) {
-    const uint32_t t = lhash_probe(area, off, shift, len, (b1 | ((b & 1u) << k)) | ((b2 | ((b >> 1) << k)) << len));
-    if (t != kFail) {
-      ++hits;
-      res = t;
-    }
+    const uint32_t kk = key[b] << ibits;
+    const uint32_t m = min3u(min3u(e[b].x ^ kk, e[b].y ^ kk, e[b].z ^ kk), min3u(e[b].w ^ kk, f[b].x ^ kk, f[b].y ^ kk),
+                             min3u(f[b].z ^ kk, f[b].w ^ kk, 0xFFFFFFFFu));
+    const bool hit = (m >> ibits) == 0u;
+    hits += hit ? 1u : 0u;
+    res = hit ? m : res;
   }
   settled = hits != 0u || max_err == 0u;
   return hits == 1u ? res : kFail;
@@ -685,24 +696,32 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
   ops.mark(3);
 
   // ---- quality filter (parse.rs:98-119, 331-375) ------------------------------------------------
-  if (pl.quality_on && !(pl.ablate & 0x8u)) {
-    const uint32_t* qual32 = ops.stage_quality();
-    ops.mark(4);
-    // after a repair the quality line is read from offset 0
-    const uint32_t qstart = repaired ? 0u : start;
-    const uint32_t avail = len - qstart;  // quality line assumed as long as the sequence line
-    const uint32_t zip = avail < pl.RL ? avail : pl.RL;
-    bool low = false;
-    for (uint32_t r = 0; r < pl.n_runs; ++r) {
-      const uint32_t ro = pl.run_off[r], rl = pl.run_len[r];
-      // a run is only evaluated when the zip continues past it (parse.rs:348-356)
-      const bool evaluated = (ro + rl) < zip;
-      const uint32_t sum = score_sum(qual32, base + (found ? qstart : 0u) + ro, rl);
-      low = low || (evaluated && sum < pl.run_thr[r]);
+  // In the reference it comes before the barcodes are looked at; here it runs while the first group
+  // chunk's table gathers are in flight.  The outcome only depends on the priority of the tests
+  // (constant region, quality, sample barcode, counted barcodes), which the order below keeps.
+  const uint32_t start_found = start;
+  bool quality_done = false;
+  auto quality_filter = [&]() {
+    quality_done = true;
+    if (pl.quality_on && !(pl.ablate & 0x8u)) {
+      const uint32_t* qual32 = ops.stage_quality();
+      ops.mark(4);
+      // after a repair the quality line is read from offset 0
+      const uint32_t qstart = repaired ? 0u : start_found;
+      const uint32_t avail = len - qstart;  // quality line assumed as long as the sequence line
+      const uint32_t zip = avail < pl.RL ? avail : pl.RL;
+      bool low = false;
+      for (uint32_t r = 0; r < pl.n_runs; ++r) {
+        const uint32_t ro = pl.run_off[r], rl = pl.run_len[r];
+        // a run is only evaluated when the zip continues past it (parse.rs:348-356)
+        const bool evaluated = (ro + rl) < zip;
+        const uint32_t sum = score_sum(qual32, base + (found ? qstart : 0u) + ro, rl);
+        low = low || (evaluated && sum < pl.run_thr[r]);
+      }
+      if (outcome == kMatched && low) outcome = kLowQuality;  // parse.rs:111
     }
-    if (outcome == kMatched && low) outcome = kLowQuality;  // parse.rs:111
-  }
-  ops.mark(5);
+    ops.mark(5);
+  };
 
   // ---- barcodes: SequenceMatchResult::new (parse.rs:439-524) -----------------------------------
   // bring the construct to bit 0 so that every capture sits at a wave-uniform position
@@ -712,12 +731,12 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
   shr_lane<NW>(P.pn, start);
   if (anyx) shr_lane<NW>(P.px, start);
   uint64_t didx = 0;
-  const bool pre_ok = active && outcome == kMatched;
+  const bool located = active && outcome == kMatched;  // anchored; the quality verdict is still to come
   const uint32_t ng = (pl.ablate & 0x20u) ? 0u : pl.n_groups;
-  // four groups at a time: first every capture is cut out and its table gather issued, then the
-  // verdicts are consumed in order -- the gathers of one read overlap instead of queueing up
+  // four groups at a time: first every capture is cut out and looked up (LDS, then the table gathers
+  // of what LDS could not answer), then the verdicts are consumed in order
   for (uint32_t g0 = 0; g0 < ng; g0 += 4) {
-    uint32_t q1[4], q2[4], qn[4], qx[4], r[4];
+    uint32_t q1[4], q2[4], qn[4], qx[4], r[4], tl[4];
     // per-lane flags of the four groups, one bit each.  Packed words (vector registers) rather than
     // bools: a bool that lives across the phase is a wave-wide mask in two scalar registers, and the
     // kernel is short of those.
@@ -726,20 +745,37 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       r[u] = kFail;
+      tl[u] = kFail;
       q1[u] = q2[u] = qn[u] = qx[u] = 0;
       if (g0 + u < ng) {  // wave-uniform
         const DevGroup& G = pl.groups[g0 + u];
         extract_planes<NW>(P, G.off, G.len, q1[u], q2[u], qn[u]);
         if (anyx) qx[u] = extract_uniform<NW>(P.px, G.off, G.len);
+      }
+    }
+    // LDS exact-match lookups of all four captures, every lane, no branches: the eight bucket reads
+    // share one round trip (a capture with 'N's simply finds nothing useful)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (g0 + u < ng) {
+        const DevGroup& G = pl.groups[g0 + u];
+        if (G.mode == kSetDirect && G.lhash_nb && ops.tables())
+          tl[u] = lhash_lookup(ops.lhash(), G, q1[u] | (q2[u] << G.len));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (g0 + u < ng) {  // wave-uniform
+        const DevGroup& G = pl.groups[g0 + u];
         if (G.mode != kSetNone) {
           const bool clean = (qn[u] | qx[u]) == 0u;
-          if (pre_ok) {
+          if (located) {
             if (G.mode == kSetDirect) {
-              const bool use_lds = G.lhash_shift && ops.tables();
+              const bool use_lds = G.lhash_nb && ops.tables();
               if (clean) {
                 // a capture that is a reference is answered from LDS; the others go to the table, unless
                 // no mismatch is allowed: then "not a reference" is already the verdict
-                if (use_lds) r[u] = lhash_lookup(ops.lhash(), G, q1[u] | (q2[u] << G.len));
+                r[u] = tl[u];
                 gather_m |= (r[u] == kFail && !(use_lds && G.lhash_complete && G.max_err == 0u)) ? (1u << u) : 0u;
               } else if (qx[u] == 0u && !G.has_odd && (qn[u] & (qn[u] - 1u)) == 0u && !(pl.ablate & 0x100u)) {
                 if (use_lds && G.lhash_complete)
@@ -776,7 +812,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
     // pending group, so one pass usually serves the whole wave whichever groups the 'N's fell into.
     while (ops.any(pend_n != 0u)) {
       const uint32_t u_sel = pend_n ? ctz(pend_n) : 0u;
-      uint32_t s_q1 = 0, s_q2 = 0, s_qn = 1u, s_off = 0, s_shift = 31u, s_len = 1u, s_max = 0;
+      uint32_t s_q1 = 0, s_q2 = 0, s_qn = 1u, s_off = 0, s_nb = 1u, s_len = 1u, s_max = 0;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (g0 + u < ng) {
@@ -786,14 +822,14 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
           s_q2 = me ? q2[u] : s_q2;
           s_qn = me ? qn[u] : s_qn;
           s_off = me ? G.lhash_off : s_off;
-          s_shift = me ? G.lhash_shift : s_shift;
+          s_nb = me ? G.lhash_nb : s_nb;
           s_len = me ? G.len : s_len;
           s_max = me ? G.max_err : s_max;
         }
       }
       bool settled = true;
       uint32_t rs = kFail;
-      if (pend_n) rs = single_n_lhash(ops.lhash(), s_off, s_shift, s_len, s_max, s_q1, s_q2, s_qn, settled);
+      if (pend_n) rs = single_n_lhash(ops.lhash(), s_off, s_nb, s_len, s_max, s_q1, s_q2, s_qn, settled);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const bool me = pend_n != 0u && u_sel == (uint32_t)u;
@@ -808,15 +844,16 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       tv[u] = 0;
-      if (g0 + u < ng && pl.groups[g0 + u].mode == kSetDirect && ops.any((gather_m >> u) & 1u)) {
+      if (g0 + u < ng && pl.groups[g0 + u].mode == kSetDirect) {  // wave-uniform: no branch between the loads
         const DevGroup& G = pl.groups[g0 + u];
         tv[u] = G.dtable()[((gather_m >> u) & 1u) ? (q1[u] | (q2[u] << G.len)) : 0u];
       }
     }
     ops.mark(6);
+    // ... and while they are, the quality lines are judged
+    if (!quality_done) quality_filter();
     // one 'N' and no substitution is a reference (or no LDS table): four table entries decide.  As
-    // above, every lane takes its lowest pending group, so the wave usually needs one round trip --
-    // and the gathers issued above are still in flight, so it is the only one.
+    // above, every lane takes its lowest pending group, so the wave usually needs one round trip.
     {
       uint32_t pend_g = gather_n_m;
       while (ops.any(pend_g != 0u)) {
@@ -846,6 +883,8 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       if ((gather_m >> u) & 1u) r[u] = (tv[u] & 0xFFFFu) == (uint32_t)kFail16 ? kFail : (tv[u] & 0xFFFFu);
+    ops.mark(7);
+    const bool pre_ok = active && outcome == kMatched;  // anchored and of good quality
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (g0 + u < ng) {
@@ -870,6 +909,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
       }
     }
   }
+  if (!quality_done) quality_filter();  // a scheme without barcode groups
   ops.groups_done();
   // ---- random barcode: kept as captured, never corrected (parse.rs:510-516) ------------------
   if (pl.has_random) {

@@ -375,7 +375,7 @@ bool bc_plan::lower(HostDevPlan& out) const {
   P.lhash_vec = 0;
   for (size_t i = 0; i < P.n_groups; ++i) {
     DevGroup& G = P.groups[i];
-    G.lhash_shift = 0;
+    G.lhash_nb = 0;
     G.lhash_off = 0;
     G.lhash_complete = 0;
     G.index = (uint32_t)i;
@@ -386,43 +386,50 @@ bool bc_plan::lower(HostDevPlan& out) const {
     for (uint32_t j = 0; j < G.n_refs; ++j)
       if (!H.rn[j] && H.rlen[j] == G.len) plain.push_back(j);
     if (plain.empty() || (ibits < 32u && G.n_refs > (1u << ibits))) continue;
-    uint32_t bbits = 1;  // at least two buckets so that the shift stays below 32
-    while ((4u << bbits) < 2u * plain.size()) ++bbits;
-    const uint32_t nbuckets = 1u << bbits;
-    if (P.lhash_vec + nbuckets > kLhashMaxVec) continue;
-    const uint32_t shift = 32u - bbits;
     auto key_of = [&](uint32_t j) { return H.r1[j] | (H.r2[j] << G.len); };
-    // two-choice placement with evictions: occupancy is at most one half, so this all but always ends
-    std::vector<uint32_t> slot_ref((size_t)nbuckets * 4, kFail);
-    std::vector<uint8_t> fill(nbuckets, 0);
-    bool complete = true;
-    uint64_t rng = 0x9E3779B97F4A7C15ull;
-    for (uint32_t j0 : plain) {
-      uint32_t j = j0;
-      bool placed = false;
-      for (int moves = 0; moves < 500 && !placed; ++moves) {
-        const uint32_t key = key_of(j);
-        const uint32_t b1 = mul24(key, kLhashMul1) >> shift, b2 = mul24(key, kLhashMul2) >> shift;
-        const uint32_t b = fill[b1] <= fill[b2] ? b1 : b2;
-        if (fill[b] < 4) {
-          slot_ref[(size_t)b * 4 + fill[b]++] = j;
-          placed = true;
-        } else {
-          rng = rng * 6364136223846793005ull + 1442695040888963407ull;
-          const uint32_t vb = (rng >> 33) & 1u ? b1 : b2;
-          const uint32_t vs = (uint32_t)(rng >> 40) & 3u;
-          std::swap(j, slot_ref[(size_t)vb * 4 + vs]);
+    // Two-choice placement with evictions into 4-entry buckets, aimed at 85 % occupancy (the scheme
+    // holds up to ~97 %); should the random walk fail, the table grows by a sixth and is rebuilt.
+    uint32_t nbuckets = std::max<uint32_t>(2u, (uint32_t)((plain.size() * 20 + 67) / 68));
+    std::vector<uint32_t> slot_ref;
+    bool complete = false;
+    for (int attempt = 0; attempt < 6 && !complete; ++attempt, nbuckets += nbuckets / 6 + 1) {
+      if (P.lhash_vec + nbuckets > kLhashMaxVec) break;
+      slot_ref.assign((size_t)nbuckets * 4, kFail);
+      std::vector<uint8_t> fill(nbuckets, 0);
+      complete = true;
+      uint64_t rng = 0x9E3779B97F4A7C15ull;
+      for (uint32_t j0 : plain) {
+        uint32_t j = j0;
+        bool placed = false;
+        for (int moves = 0; moves < 2000 && !placed; ++moves) {
+          const uint32_t key = key_of(j);
+          const uint32_t b1 = lhash_bucket(key, kLhashMul1, nbuckets), b2 = lhash_bucket(key, kLhashMul2, nbuckets);
+          const uint32_t b = fill[b1] <= fill[b2] ? b1 : b2;
+          if (fill[b] < 4) {
+            slot_ref[(size_t)b * 4 + fill[b]++] = j;
+            placed = true;
+          } else {
+            rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+            const uint32_t vb = (rng >> 33) & 1u ? b1 : b2;
+            const uint32_t vs = (uint32_t)(rng >> 40) & 3u;
+            std::swap(j, slot_ref[(size_t)vb * 4 + vs]);
+          }
+        }
+        if (!placed) {
+          complete = false;
+          break;
         }
       }
-      if (!placed) complete = false;  // that reference is then only known to dtable
+      if (complete) break;
     }
+    if (!complete) continue;  // no LDS table for this group: every capture goes to dtable
     const uint32_t filler = (key_of(plain[0]) << ibits) | plain[0];
     std::vector<uint32_t> img((size_t)nbuckets * 4, filler);
     for (size_t i = 0; i < slot_ref.size(); ++i)
       if (slot_ref[i] != kFail) img[i] = (key_of(slot_ref[i]) << ibits) | slot_ref[i];
-    G.lhash_shift = shift;
+    G.lhash_nb = nbuckets;
     G.lhash_off = P.lhash_vec;
-    G.lhash_complete = complete ? 1u : 0u;
+    G.lhash_complete = 1u;
     out.lhash.insert(out.lhash.end(), img.begin(), img.end());
     P.lhash_vec += nbuckets;
   }
