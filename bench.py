@@ -137,7 +137,7 @@ def main():
             # the per-tuple distinct counts may be summed (done by the root at output time)
             fixed_counters = bcdist.finish_random(eng, dev, dst=0)
         else:
-            bcdist.reduce_table(table, dst=0)  # the job's single RCCL reduce of the counter tables
+            bcdist.reduce_table(table, dst=0)  # the job's one exchange: all-to-all sum of the counter tables
         torch.cuda.synchronize()
         reduce_ms = (time.perf_counter() - tr) * 1e3
     barrier()
@@ -209,7 +209,7 @@ def main():
         "dtype": "u8",
         "data": "synthetic",
         "config": {"workload": WORKLOAD_TEXT[args.config], "config": args.config, "reads_per_step_per_gpu": n,
-                   "read_len": R, "parallelism": "reads sharded over %d GPU(s); 1 RCCL sum-reduce of the counter table" % world},
+                   "read_len": R, "parallelism": "reads sharded over %d GPU(s); one all-to-all sum of the counter tables over xGMI at the end" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "alg_bytes_per_launch": b_alg * n, "kernel": eng.kernel_name(),

@@ -189,3 +189,38 @@ def test_two_ranks_count_map_merge(tmp_path):
     out = str(tmp_path / "result.txt")
     mp.spawn(_worker_counts, args=(2, _free_port(), out), nprocs=2, join=True)
     assert open(out).read() == "ok;ok;"
+
+
+def _worker_table(rank, world, port, out_path):
+    """the all-to-all sum of dense tables (distributed.reduce_table) against torch.distributed.reduce"""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import ngs_barcode_count_amd.distributed as bcdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = True
+    for n in (1, 2, 7, 1000, 4097):
+        for dst in range(world):
+            rng = np.random.default_rng(1000 * rank + n)
+            mine = torch.from_numpy(rng.integers(0, 2**31 - 1, size=n).astype(np.int32))
+            a, b = mine.clone(), mine.clone()
+            bcdist.reduce_table(a, dst=dst, method="alltoall")
+            bcdist.reduce_table(b, dst=dst, method="reduce")
+            if rank == dst:
+                ok = ok and bool((a == b).all())  # wraps identically (u32 sums)
+    res = [None] * world
+    dist.all_gather_object(res, ok)
+    if rank == 0:
+        with open(out_path, "w") as f:
+            f.write("ok" if all(res) else "MISMATCH")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_table_all_to_all_sum(tmp_path, world):
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_worker_table, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert open(out).read() == "ok"
