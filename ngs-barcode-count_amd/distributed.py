@@ -15,38 +15,37 @@ def shard(n_total, rank, world):
     return first, base + (1 if rank < extra else 0)
 
 
-def table_slices(n, world):
-    """how the dense table is cut for the all-to-all sum: world contiguous slices, sizes differ by at most one"""
-    return [shard(n, r, world)[1] for r in range(world)]
-
-
 def reduce_table(table, dst=0, method=None):
     """Sum of every rank's dense u32 counter table (viewed as int32: same bits) onto rank dst, in place
     there.  On xGMI every GPU has its own link to every other, so the default is not a ring:
-      1. all-to-all: rank r receives slice r of every table (7 peers at once, one link each),
-      2. each rank adds up the world slices it received (HBM-speed, local),
-      3. the summed slices travel to dst, again over one link each.
+      1. all-to-all (equal slices): rank r receives slice r of every table, 7 peers at once, one link each,
+      2. each rank adds up the slices it received (local, HBM speed),
+      3. the summed slices are sent to dst point to point, again one link each.
     A ring reduce would push the whole 16 GB table of the DEL workloads through one link's bandwidth.
-    method="reduce" keeps torch.distributed.reduce (what the gloo tests of old checked; any backend)."""
+    Tables whose length is not a multiple of the world size, and method="reduce" /
+    BC_TABLE_REDUCE=reduce, use torch.distributed.reduce."""
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return table
     import os
+    world, rank = dist.get_world_size(), dist.get_rank()
     method = method or os.environ.get("BC_TABLE_REDUCE", "alltoall")
-    if method == "reduce":
+    n = table.numel()
+    if method == "reduce" or n % world or n == 0:
         dist.reduce(table, dst=dst, op=dist.ReduceOp.SUM)
         return table
-    world, rank = dist.get_world_size(), dist.get_rank()
-    n = table.numel()
-    sizes = table_slices(n, world)
-    mine = sizes[rank]
-    recv = torch.empty(mine * world, dtype=table.dtype, device=table.device)
-    dist.all_to_all_single(recv, table, [mine] * world, sizes)
+    mine = n // world
+    recv = torch.empty(n, dtype=table.dtype, device=table.device)
+    dist.all_to_all_single(recv, table)
     part = recv[:mine]
     for r in range(1, world):  # in-place 32-bit adds: wrap like the u32 counters they are
         part += recv[r * mine:(r + 1) * mine]
-    # summed slice r -> dst, landing at its place in dst's table
-    dist.all_to_all_single(table if rank == dst else torch.empty(0, dtype=table.dtype, device=table.device), part,
-                           sizes if rank == dst else [0] * world, [mine if r == dst else 0 for r in range(world)])
+    if rank == dst:
+        table[dst * mine:(dst + 1) * mine].copy_(part)
+        ops = [dist.P2POp(dist.irecv, table[r * mine:(r + 1) * mine], r) for r in range(world) if r != dst]
+    else:
+        ops = [dist.P2POp(dist.isend, part, dst)]
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
     return table
 
 
