@@ -182,13 +182,16 @@ int bc_engine_kernel_ms(bc_engine *e, double *total_ms, uint64_t *launches);
  * "bc_jit_match_count<NW,NWW>" (the one specialised to this plan's scheme); "" before the first submit. */
 const char *bc_engine_kernel_name(bc_engine *e);
 
-/* Scheme-specialised kernels.  For batches of 2^20 reads or more an engine runs a kernel compiled for
- * its plan's scheme (offsets, shift programs, thresholds and set sizes as immediates).  The code
- * object is looked up in jit_cache/ next to the library and in $BC_JIT_CACHE; if absent it is
- * compiled on first use (ROCm's hipcc as a child process, else hiprtc in-process) and stored there.
- * When neither is available the engine says so on stderr and keeps using the generic kernel -- same
- * results, about 15 % slower.  Environment: BC_JIT=0 (never) | 1 (default) | force (any batch
- * size) | cached (cache hits only, never compile).
+/* Scheme-specialised kernels.  Next to the generic kernel (any plan, plan read from memory) an engine
+ * can run one compiled for its plan's scheme (offsets, shift programs, thresholds and set sizes as
+ * immediates; ~15-25 % faster).  The code object is looked up by content hash in jit_cache/ next to
+ * the library and in $BC_JIT_CACHE: a hit is used from the first submit on.  On a miss the engine
+ * keeps counting with the generic kernel and, once 2^20 reads have been submitted, compiles the
+ * specialised one on a worker thread (ROCm's hipcc as a child process, else hiprtc in-process), stores
+ * it in the cache and switches over at the next submit after it is ready.  Results are identical
+ * either way.  If no compiler is available the engine says so once on stderr.
+ * Environment: BC_JIT=0 (never) | 1 (default) | force (compile synchronously at the first submit) |
+ * cached (cache hits only).
  * bc_plan_precompile builds the kernel ahead of time without touching a GPU: nw = 32-base words per
  * read (4 covers reads up to 128 bases; only nw = 4 is specialised today), nww = words of candidate
  * offsets ((read_len - scheme_len + 1 + 31) / 32), with_lens = per-read lengths will be passed,

@@ -1,5 +1,7 @@
 """BASELINE.json configs on the GPU: oracle parity on a seeded sample, and size-independent
 properties at full size (one outcome per read, table sum = matched, shard additivity, determinism)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -92,3 +94,48 @@ def test_full_size_properties(name, n):
     assert key(s, b, cnt) == key(s2, b2, cnt2)
     whole.close()
     halves.close()
+
+
+def test_specialised_kernel_takes_over_in_the_background(monkeypatch, tmp_path):
+    """default mode, empty kernel cache: small batches start on the generic kernel; after 2^20 reads the
+    specialised one is compiled on a worker thread and later submits switch to it -- same counts."""
+    import time
+    import torch
+    import ngs_barcode_count_amd as pkg
+    import workloads
+    monkeypatch.setenv("BC_JIT", "1")
+    monkeypatch.setenv("BC_JIT_CACHE", str(tmp_path / "cache"))
+    w = workloads.make("config3", n_sets=(4, 37, 41, 43))  # a shape no other test (or build()) has cached
+    n, R = 400_000, w.read_len
+    dseq = torch.empty(n * R, dtype=torch.uint8, device="cuda")
+    dqual = torch.empty(n * R, dtype=torch.uint8, device="cuda")
+    w.synth.generate_device(0, None, 0, n, dseq.data_ptr(), dqual.data_ptr())
+    torch.cuda.synchronize()
+    ref = pkg.Engine(w.plan, device=0)
+    ref.submit_device(dseq.data_ptr(), dqual.data_ptr(), n, R, R)
+    one = ref.counters()
+    assert ref.kernel_name().startswith("match_count_kernel")  # below the threshold: nothing compiled
+    ref.close()
+    eng = pkg.Engine(w.plan, device=0)
+    names, batches, t0 = [], 0, time.time()
+    while time.time() - t0 < 120:
+        eng.submit_device(dseq.data_ptr(), dqual.data_ptr(), n, R, R)
+        eng.sync()
+        batches += 1
+        names.append(eng.kernel_name())
+        if names[-1].startswith("bc_jit_match_count") and batches >= 6:
+            break
+        time.sleep(0.2)
+    assert names[0].startswith("match_count_kernel"), names[:3]
+    assert names[-1].startswith("bc_jit_match_count"), (names[-3:], batches)
+    got = eng.counters()
+    for k, v in one.items():
+        assert got[k] == v * batches, (k, got, one, batches)
+    assert os.listdir(str(tmp_path / "cache"))  # the code object was stored for the next run
+    eng.close()
+    # a second engine finds it in the cache and starts on the specialised kernel
+    eng2 = pkg.Engine(w.plan, device=0)
+    eng2.submit_device(dseq.data_ptr(), dqual.data_ptr(), n, R, R)
+    assert eng2.kernel_name().startswith("bc_jit_match_count")
+    assert eng2.counters() == one
+    eng2.close()
