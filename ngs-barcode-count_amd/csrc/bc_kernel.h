@@ -250,7 +250,23 @@ __device__ __forceinline__ void wait_vm_keep(uint32_t keep) {
     case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
     case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
     case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 25: asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); break;
+    case 26: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
+    case 27: asm volatile("s_waitcnt vmcnt(27)" ::: "memory"); break;
+    case 28: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+    case 29: asm volatile("s_waitcnt vmcnt(29)" ::: "memory"); break;
+    case 30: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;
+    case 31: asm volatile("s_waitcnt vmcnt(31)" ::: "memory"); break;
+    case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+    case 33: asm volatile("s_waitcnt vmcnt(33)" ::: "memory"); break;
+    case 34: asm volatile("s_waitcnt vmcnt(34)" ::: "memory"); break;
+    case 35: asm volatile("s_waitcnt vmcnt(35)" ::: "memory"); break;
+    case 36: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
+    case 37: asm volatile("s_waitcnt vmcnt(37)" ::: "memory"); break;
+    case 38: asm volatile("s_waitcnt vmcnt(38)" ::: "memory"); break;
+    case 39: asm volatile("s_waitcnt vmcnt(39)" ::: "memory"); break;
+    case 40: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;  // 0, or more than the ladder knows: wait for all
   }
 }
 
@@ -296,10 +312,12 @@ struct DeviceOps {
   }
   __device__ __forceinline__ uint32_t bytes_per_read() const { return stride_; }
   uint32_t stride_;
-  __device__ __forceinline__ const uint32_t* stage_quality() const {
+  // younger: loads the lane code itself has in flight (issued after everything below)
+  __device__ __forceinline__ const uint32_t* stage_quality(uint32_t younger) const {
     if (qual_async) {
-      // issued before this tile's sequence fetch of the next tile: everything but that fetch has landed
-      wait_vm_keep(((next_seq && !late_fetch) ? chunks : 0u) + pending_add);
+      // requested before the previous tile's counter atomic and the next tile's sequence lines: those
+      // (and the caller's own loads) may stay in flight
+      wait_vm_keep(((next_seq && !late_fetch) ? chunks : 0u) + pending_add + younger);
       wave_lds_fence();
       return reinterpret_cast<const uint32_t*>(qtile);
     }

@@ -631,7 +631,7 @@ struct ReadResult {
 //   void mark(int)                               -- profiling hook (no-op outside BC_PROFILE builds)
 //   const Quad* lhash(), bool tables()           -- the LDS exact-match area (plan.lhash_vec uint4s), and whether
 //                                                   it is loaded
-//   const uint32_t* stage_quality()              -- called once, by every lane, when the quality filter is
+//   const uint32_t* stage_quality(uint32_t)      -- called once, by every lane, when the quality filter is
 //                                                   on: returns where the quality lines are
 // NW = 32-base words per read; NWW = words of candidate offsets / repair windows (len - L + 1 <= 32*NWW)
 template <class Ops, int NW, int NWW>
@@ -701,10 +701,12 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
   // (constant region, quality, sample barcode, counted barcodes), which the order below keeps.
   const uint32_t start_found = start;
   bool quality_done = false;
-  auto quality_filter = [&]() {
+  // in_flight: vector-memory loads this lane code has issued and not yet consumed (they are younger than
+  // the quality fetch and need not land for it)
+  auto quality_filter = [&](uint32_t in_flight) {
     quality_done = true;
     if (pl.quality_on && !(pl.ablate & 0x8u)) {
-      const uint32_t* qual32 = ops.stage_quality();
+      const uint32_t* qual32 = ops.stage_quality(in_flight);
       ops.mark(4);
       // after a repair the quality line is read from offset 0
       const uint32_t qstart = repaired ? 0u : start_found;
@@ -841,17 +843,19 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
     // correction-table gathers of the captures LDS did not answer: all lanes load (the idle ones entry
     // 0, one shared cache line), so the four loads are in flight together
     uint32_t tv[4];
+    uint32_t n_gathers = 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       tv[u] = 0;
       if (g0 + u < ng && pl.groups[g0 + u].mode == kSetDirect) {  // wave-uniform: no branch between the loads
         const DevGroup& G = pl.groups[g0 + u];
+        ++n_gathers;
         tv[u] = G.dtable()[((gather_m >> u) & 1u) ? (q1[u] | (q2[u] << G.len)) : 0u];
       }
     }
     ops.mark(6);
     // ... and while they are, the quality lines are judged
-    if (!quality_done) quality_filter();
+    if (!quality_done) quality_filter(n_gathers);
     // one 'N' and no substitution is a reference (or no LDS table): four table entries decide.  As
     // above, every lane takes its lowest pending group, so the wave usually needs one round trip.
     {
@@ -909,7 +913,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
       }
     }
   }
-  if (!quality_done) quality_filter();  // a scheme without barcode groups
+  if (!quality_done) quality_filter(0u);  // a scheme without barcode groups
   ops.groups_done();
   // ---- random barcode: kept as captured, never corrected (parse.rs:510-516) ------------------
   if (pl.has_random) {

@@ -19,7 +19,7 @@ struct HostOps {
   const bc::Quad* area = nullptr;
   const bc::Quad* lhash() const { return area; }
   bool tables() const { return area != nullptr; }
-  const uint32_t* stage_quality() const { return qual32; }
+  const uint32_t* stage_quality(uint32_t) const { return qual32; }
   void sequence_consumed() const {}
   void mark(int) const {}
   void groups_done() const {}
