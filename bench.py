@@ -147,6 +147,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, t_steps, reduce_ms = t.tolist()
 
+    sclk = eng.sclk_mhz()  # straight after the timed steps: the clock the kernels actually ran at
     kernel_ms, launches = eng.kernel_ms()
     counters = fixed_counters if fixed_counters is not None else bcdist.reduce_counters(eng.counters(), dev, dst=0)
     total_reads = n * args.steps * world
@@ -215,7 +216,7 @@ def main():
                      "alg_bytes_per_launch": b_alg * n, "kernel": eng.kernel_name(),
                      "kernel_avg_ms": avg_ms, "launches": launches, "alg_bytes_per_read": b_alg,
                      "kernel_reads_per_s": n / (avg_ms * 1e-3) if avg_ms > 0 else 0.0,
-                     "box_copy_GBps": box_copy,
+                     "box_copy_GBps": box_copy, "sclk_mhz": sclk,
                      "frac_of_box_copy": (achieved / box_copy) if box_copy else None},
         "outcomes": {k: counters[k] for k in pkg.COUNTER_NAMES},
         "reduce_ms": reduce_ms,

@@ -181,6 +181,10 @@ int bc_engine_kernel_ms(bc_engine *e, double *total_ms, uint64_t *launches);
 /* Which kernel the last submit launched: "match_count_kernel<NW,NWW>" (the generic one, any plan) or
  * "bc_jit_match_count<NW,NWW>" (the one specialised to this plan's scheme); "" before the first submit. */
 const char *bc_engine_kernel_name(bc_engine *e);
+/* Shader clock right now (MHz), measured by a 0.3 ms probe kernel on the engine's stream against the
+ * 100 MHz reference counter.  Call it straight after the work of interest: the clock sags under power
+ * and thermal limits, and the match kernel's time follows it. */
+int bc_engine_sclk_mhz(bc_engine *e, double *mhz);
 
 /* Scheme-specialised kernels.  Next to the generic kernel (any plan, plan read from memory) an engine
  * can run one compiled for its plan's scheme (offsets, shift programs, thresholds and set sizes as

@@ -217,6 +217,12 @@ class Engine:
     def kernel_name(self):
         return self._lib.bc_engine_kernel_name(self._e).decode()
 
+    def sclk_mhz(self):
+        """shader clock right now (0.3 ms probe kernel)"""
+        v = C.c_double()
+        _check(self._lib, self._lib.bc_engine_sclk_mhz(self._e, C.byref(v)))
+        return v.value
+
     def kernel_ms(self):
         ms, n = C.c_double(), C.c_uint64()
         _check(self._lib, self._lib.bc_engine_kernel_ms(self._e, C.byref(ms), C.byref(n)))

@@ -73,6 +73,7 @@ ENGINE_API = {
     "bc_engine_timing": (_int, [_vp, _int]),
     "bc_engine_kernel_ms": (_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "bc_engine_kernel_name": (_cp, [_vp]),
+    "bc_engine_sclk_mhz": (_int, [_vp, C.POINTER(C.c_double)]),
     "bc_plan_precompile": (_int, [_vp, _int, _int, _int, _cp]),  # lives with the engine: it drives the device compiler
     "bc_engine_trace": (_int, [_vp, _vp, _vp]),
     "bc_engine_row_text": (_int, [_vp, _u64, _cp, _sz, _cp, _sz, C.POINTER(C.c_uint64)]),
