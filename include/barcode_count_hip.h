@@ -197,7 +197,7 @@ int bc_engine_sclk_mhz(bc_engine *e, double *mhz);
  * Environment: BC_JIT=0 (never) | 1 (default) | force (compile synchronously at the first submit) |
  * cached (cache hits only).
  * bc_plan_precompile builds the kernel ahead of time without touching a GPU: nw = 32-base words per
- * read (4 covers reads up to 128 bases; only nw = 4 is specialised today), nww = words of candidate
+ * read (4: reads up to 128 bases, 8: up to 256; longer reads stay on the generic kernel), nww = words of candidate
  * offsets ((read_len - scheme_len + 1 + 31) / 32), with_lens = per-read lengths will be passed,
  * cache_dir NULL = next to the library. */
 int bc_plan_precompile(const bc_plan *p, int nw, int nww, int with_lens, const char *cache_dir);

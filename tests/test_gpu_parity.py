@@ -76,7 +76,7 @@ def kernel(request, monkeypatch, tmp_path_factory):
 def check_kernel(eng, kernel):
     name = eng.kernel_name()
     nw, nww = (int(v) for v in name[name.index("<") + 1:-1].split(","))
-    if kernel == "specialised" and nw == 4 and nww <= 2:
+    if kernel == "specialised" and nw <= 8 and nww <= 4:
         assert name.startswith("bc_jit_match_count"), name
     else:
         assert name.startswith("match_count_kernel"), name
@@ -206,7 +206,8 @@ def test_kat_reads_on_device():
         eng.close()
 
 
-def test_long_reads_and_odd_strides():
+@pytest.mark.parametrize("kernel", ["generic", "specialised"], indirect=True)
+def test_long_reads_and_odd_strides(kernel):
     for rl, stride in ((150, 152), (250, 251), (300, 304), (75, 77)):
         c = cases.build_case("del_mismatch_quality", seed=rl, n=10)
         rng = np.random.default_rng(rl)
@@ -216,6 +217,7 @@ def test_long_reads_and_odd_strides():
         seq, qual, lens = readgen.to_arrays(c["reads"], stride=stride)
         eng, outc, idx = run_device(plan, seq, qual, None, stride, rl)
         parity.check_per_read(c, plan, outc, idx, False)
+        check_kernel(eng, kernel)
         eng.close()
 
 

@@ -12,12 +12,12 @@ class Workload:
     pass
 
 
-def make(name, n_sets=None, lib=None, n_molecules=None):
+def make(name, n_sets=None, lib=None, n_molecules=None, read_len=100):
     """name: config2 | config3 | config5.  n_sets = (samples, refs per counted barcode...) overrides the
     BASELINE sizes (tests use smaller sets so the CPU oracle stays fast)."""
     w = Workload()
     w.name = name
-    w.read_len = 100
+    w.read_len = read_len
     if name in ("config2", "config3"):
         sizes = n_sets or (4, 1000, 1000, 1000)
         w.scheme = DEL_SCHEME
