@@ -616,6 +616,74 @@ BC_HD uint32_t single_n_lhash(const Quad* __restrict__ area, uint32_t off, uint3
   return hits == 1u ? res : kFail;
 }
 
+// First tier of the search in a large set (bc_device_plan.h): every reference within one mismatch of
+// the N-free capture (q1, q2) sits in one of its two buckets, so a lane that finds one there knows the
+// minimum distance (0 or 1) and how many references have it.  settled = false: nothing that near --
+// the pigeonhole search over all budget+1 blocks has to decide.
+BC_HD void tier_probe(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t& best, uint32_t& cnt, uint32_t& idx) {
+  const uint32_t blen = G.tier_blen, bm = (1u << blen) - 1u, nbk = 1u << (2u * blen);
+  const BC_GLOBAL uint32_t* off = G.tier_off();
+  const BC_GLOBAL uint32_t* list = G.tier_list();
+  uint32_t beg[2], end[2];
+#pragma unroll
+  for (uint32_t b = 0; b < 2; ++b) {
+    const uint32_t sh = b * G.tier_stride;
+    const uint32_t val = ((q1 >> sh) & bm) | (((q2 >> sh) & bm) << blen);
+    beg[b] = off[b * (nbk + 1u) + val];
+    end[b] = off[b * (nbk + 1u) + val + 1u];
+  }
+  best = 0xFFFFFFFFu;
+  cnt = 0;
+  idx = kFail;
+#pragma unroll
+  for (uint32_t b = 0; b < 2; ++b) {
+    for (uint32_t i = beg[b]; i < end[b]; ++i) {
+      const BC_GLOBAL uint32_t* e = list + ((size_t)b * G.n_idx + i) * 4u;
+      const uint32_t diff = (q1 ^ e[0]) | (q2 ^ e[1]);
+      if (b == 1u && (diff & bm) == 0u) continue;  // equal on block 0 too: met there
+      const uint32_t d = popc(diff);
+      if (d < best) {
+        best = d;
+        cnt = 1;
+        idx = e[2];
+      } else if (d == best) {
+        ++cnt;
+      }
+    }
+  }
+}
+
+BC_HD uint32_t tier_lookup(const DevGroup& G, uint32_t q1, uint32_t q2, bool& settled) {
+  uint32_t best, cnt, idx;
+  tier_probe(G, q1, q2, best, cnt, idx);
+  settled = best <= 1u;
+  return (settled && cnt == 1u && best <= G.max_err) ? idx : kFail;
+}
+
+// The same for a capture with one 'N': 'N' is free (parse.rs:569), so a reference's distance to the
+// capture is its distance to the substitution that carries the reference's own base there -- every
+// reference shows up at its true distance under exactly one of the four substitutions.  Hence the
+// minimum over the four probes is the minimum distance, and the references at it are the probes' counts
+// added up.
+BC_HD uint32_t tier_lookup_single_n(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t qn, bool& settled) {
+  const uint32_t k = ctz(qn);
+  const uint32_t b1 = q1 & ~qn, b2 = q2 & ~qn;
+  uint32_t best = 0xFFFFFFFFu, total = 0, res = kFail;
+  for (uint32_t b = 0; b < 4; ++b) {
+    uint32_t sb, sc, si;
+    tier_probe(G, b1 | ((b & 1u) << k), b2 | ((b >> 1) << k), sb, sc, si);
+    if (sb < best) {
+      best = sb;
+      total = sc;
+      res = si;
+    } else if (sb == best) {
+      total += sc;
+    }
+  }
+  settled = best <= 1u;
+  return (settled && total == 1u && best <= G.max_err) ? res : kFail;
+}
+
 // ---- the per-read decision tree ---------------------------------------------------------------
 struct ReadResult {
   uint32_t outcome;    // Outcome; kMatched means "passed every test" (duplicate detection is later)
@@ -789,6 +857,14 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
               }
             } else if (G.mode == kSetHash) {
               need_m |= 1u << u;
+              if (!clean && qx[u] == 0u && (qn[u] & (qn[u] - 1u)) == 0u && G.tier_blen && !(pl.ablate & 0x800u)) {
+                bool settled = false;
+                const uint32_t t = tier_lookup_single_n(G, q1[u], q2[u], qn[u], settled);
+                if (settled) {
+                  r[u] = t;
+                  need_m &= ~(1u << u);
+                }
+              }
               if (clean) {
                 const uint64_t key = (uint64_t)q1[u] | ((uint64_t)q2[u] << 32);
                 uint32_t h = (uint32_t)hash64(key) & G.hmask;
@@ -801,6 +877,15 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
                     break;
                   }
                   h = (h + 1u) & G.hmask;
+                }
+                // not a reference: is one a single mismatch away?  (each lane searches for itself)
+                if (((need_m >> u) & 1u) && G.tier_blen && !(pl.ablate & 0x800u)) {
+                  bool settled = false;
+                  const uint32_t t = tier_lookup(G, q1[u], q2[u], settled);
+                  if (settled) {
+                    r[u] = t;
+                    need_m &= ~(1u << u);
+                  }
                 }
               }
             } else {

@@ -367,6 +367,29 @@ bool bc_plan::lower(HostDevPlan& out) const {
         G.seed_blen = blen;
         G.n_idx = (uint32_t)plain.size();
         G.n_odd = (uint32_t)H.odd_list.size();
+        // first tier (see bc_device_plan.h): two blocks, one per half of the barcode
+        const uint32_t tb = std::min<uint32_t>(8u, G.len / 2u);
+        if (G.max_err >= 1 && tb >= 4 && H.odd_list.empty()) {
+          const uint32_t tnbk = 1u << (2 * tb), tbm = (1u << tb) - 1, stride = G.len / 2u;
+          H.tier_off.assign((size_t)2 * (tnbk + 1), 0);
+          H.tier_list.assign((size_t)2 * plain.size() * 4, 0);
+          for (uint32_t b = 0; b < 2; ++b) {
+            const uint32_t sh = b * stride;
+            auto value = [&](uint32_t j) { return ((H.r1[j] >> sh) & tbm) | (((H.r2[j] >> sh) & tbm) << tb); };
+            uint32_t* off = &H.tier_off[(size_t)b * (tnbk + 1)];
+            for (uint32_t j : plain) off[value(j) + 1]++;
+            for (uint32_t v = 0; v < tnbk; ++v) off[v + 1] += off[v];
+            std::vector<uint32_t> cur(off, off + tnbk);
+            for (uint32_t j : plain) {
+              uint32_t* e = &H.tier_list[((size_t)b * plain.size() + cur[value(j)]++) * 4];
+              e[0] = H.r1[j];
+              e[1] = H.r2[j];
+              e[2] = j;
+            }
+          }
+          G.tier_blen = tb;
+          G.tier_stride = stride;
+        }
       }
     }
   }

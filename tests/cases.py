@@ -64,6 +64,13 @@ def build_case(name, seed=0, n=600):
         c["samples"] = None
         c["counted"] = [readgen.make_set(rng, 400, 20, 3)]
         c["reads"] = readgen.gen_reads(rng, CRISPR_SCHEME, n, 100, None, c["counted"], p_sub=0.03, p_n=0.003)
+    elif name == "large_set_ties":
+        # a large set (hash + tiered search path) whose members are only two mismatches apart: captures one
+        # mismatch from TWO references (a tie -> no match) occur next to uniquely correctable ones
+        c["scheme"] = "TTGTGGAAAGGACGAAACACCG{16}GTTTTAGAGCTAGAAATAGCAAGTT"
+        c["samples"] = None
+        c["counted"] = [readgen.make_set(rng, 600, 16, 2)]
+        c["reads"] = readgen.gen_reads(rng, c["scheme"], n, 100, None, c["counted"], p_sub=0.04, p_n=0.003)
     elif name == "fmtn":
         # scheme with N positions: [AGCT] in the regex, wildcard in repair, regions_string shift (Q9)
         c["scheme"] = FMTN_SCHEME
@@ -143,7 +150,7 @@ def build_case(name, seed=0, n=600):
 
 
 ALL_CASES = ["del_exact", "del_mismatch_quality", "del_dense_ties", "del_random", "example_files",
-             "example_files_samples", "crispr", "fmtn", "nosample_with_sample_file", "nosample",
+             "example_files_samples", "crispr", "large_set_ties", "fmtn", "nosample_with_sample_file", "nosample",
              "refs_with_n_and_ragged", "other_chars", "long_gaps", "example_files_random_nosample", "raw_counted",
              "raw_sample", "raw_all_random"]
 

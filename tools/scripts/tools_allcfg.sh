@@ -9,7 +9,7 @@ import json,sys
 d=json.loads(sys.stdin.read()); print('$cfg $label', 'kernel_ms %.3f' % d['roofline']['kernel_avg_ms'], 'Greads/s %.2f' % (d['roofline']['kernel_reads_per_s']/1e9), 'value %.3g' % d['value'])
 " | tee -a gpurun_out/allcfg.txt
 }
-for cfg in config3 config4; do
+for cfg in config5; do
   n=20000000
   run "prev" $cfg $n BC_LIB=$PWD/build_variants/libprev.so BC_JIT=0
   run "generic" $cfg $n BC_JIT=0
