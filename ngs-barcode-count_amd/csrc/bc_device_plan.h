@@ -21,7 +21,7 @@ extern "C" __constant__ uint64_t bc_jit_addr[];
 namespace bc {
 
 constexpr int kMaxGroups = 18;
-constexpr int kAddrPerGroup = 12;  // address fields of a DevGroup, in declaration order
+constexpr int kAddrPerGroup = 15;  // address fields of a DevGroup, in declaration order
 constexpr int kPlanAddrs = 1;      // ... of the DevPlan itself    // sample + 16 counted barcodes + random
 constexpr int kMaxEntries = 160;  // program entries per position class (up to three positions each)
 constexpr int kMaxRuns = 40;      // quality runs of regions_string
@@ -87,10 +87,18 @@ struct DevGroup {
   // and tier_stride.  A reference within ONE mismatch of a capture equals it on one of them, and with
   // 4^8 buckets per block a bucket holds a handful of references at most: every LANE looks its own
   // capture up (bc_lane.h tier_lookup).  Nothing within one mismatch -> the pigeonhole search above.
+  // ... and a coarser pigeonhole index in front of the full one: seed2_nb = 3 longer blocks catch every
+  // reference within two mismatches with buckets an order of magnitude shorter
+  uint32_t seed2_nb;      // 0: none
+  uint32_t seed2_blen;
+  uint64_t seed2_off_a;
+  uint64_t seed2_list_a;
   uint32_t tier_blen;     // 0: no tier index
   uint32_t tier_stride;
   uint64_t tier_off_a;    // [2][4^tier_blen + 1] bucket starts
   uint64_t tier_list_a;   // [2][n_idx] entries {r1, r2, index, 0}
+  uint64_t tier_bkt_a;    // [2][4^tier_blen][4] the first four entries of every bucket, one 64-byte line each:
+                          // {r1, r2, index, references in the bucket}; the rest of a longer bucket is in tier_list
   // kSetDirect, small sets: the plain references also sit in an LDS-resident exact-match table of
   // 4-entry buckets, entry = capture key << ibits | reference index with ibits = 32 - 2 * len.  A key
   // lives in one of its two buckets (two multiplicative hashes), so a lookup is two 16-byte LDS reads.
@@ -113,6 +121,9 @@ struct DevGroup {
   BC_HD const BC_GLOBAL uint32_t* seed_off() const { return reinterpret_cast<const BC_GLOBAL uint32_t*>(BC_ADDR(seed_off_a, 7)); }
   BC_HD const BC_GLOBAL uint32_t* seed_list() const { return reinterpret_cast<const BC_GLOBAL uint32_t*>(BC_ADDR(seed_list_a, 8)); }
   BC_HD const BC_GLOBAL uint32_t* odd_list() const { return reinterpret_cast<const BC_GLOBAL uint32_t*>(BC_ADDR(odd_list_a, 9)); }
+  BC_HD const BC_GLOBAL uint32_t* seed2_off() const { return reinterpret_cast<const BC_GLOBAL uint32_t*>(BC_ADDR(seed2_off_a, 12)); }
+  BC_HD const BC_GLOBAL uint32_t* seed2_list() const { return reinterpret_cast<const BC_GLOBAL uint32_t*>(BC_ADDR(seed2_list_a, 13)); }
+  BC_HD const BC_GLOBAL uint32_t* tier_bkt() const { return reinterpret_cast<const BC_GLOBAL uint32_t*>(BC_ADDR(tier_bkt_a, 14)); }
   BC_HD const BC_GLOBAL uint32_t* tier_off() const { return reinterpret_cast<const BC_GLOBAL uint32_t*>(BC_ADDR(tier_off_a, 10)); }
   BC_HD const BC_GLOBAL uint32_t* tier_list() const { return reinterpret_cast<const BC_GLOBAL uint32_t*>(BC_ADDR(tier_list_a, 11)); }
 };

@@ -67,20 +67,20 @@ __device__ __forceinline__ uint32_t wave_fix_error(const DevGroup& G, uint32_t q
 // The capture must be free of 'N' / foreign bytes.
 // Returns the smallest key (distance + 1, 0 for the capture itself), whether exactly one reference
 // has it, and that reference.
-__device__ __forceinline__ void wave_seeded_min(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t& kmin_out,
-                                                bool& unique_out, uint32_t& idx_out) {
-  const uint32_t nb = G.seed_nb, blen = G.seed_blen, bm = (1u << blen) - 1u;
+// one pigeonhole index: nb blocks of blen bases from bit 0.  Returns true when the search is decided
+// (the best distance found is <= the number of blocks finished, see below); s accumulates the candidates.
+__device__ __forceinline__ bool wave_scan_blocks(uint32_t nb, uint32_t blen, const BC_GLOBAL uint32_t* off_base,
+                                                 const BC_GLOBAL uint32_t* list_base, uint32_t n_idx, uint32_t q1, uint32_t q2,
+                                                 Nearest& s) {
+  const uint32_t bm = (1u << blen) - 1u;
   const uint32_t nbk = 1u << (2 * blen);
   const uint32_t lane = __lane_id();
-  const BC_GLOBAL uint4* entries = reinterpret_cast<const BC_GLOBAL uint4*>(G.seed_list());
-  Nearest s;
-  nearest_init(s);
+  const BC_GLOBAL uint4* entries = reinterpret_cast<const BC_GLOBAL uint4*>(list_base);
   for (uint32_t b = 0; b < nb; ++b) {
     const uint32_t val = ((q1 >> (b * blen)) & bm) | (((q2 >> (b * blen)) & bm) << blen);
-    const BC_GLOBAL uint32_t* off = G.seed_off() + (size_t)b * (nbk + 1);
+    const BC_GLOBAL uint32_t* off = off_base + (size_t)b * (nbk + 1);
     const uint32_t beg = off[val], end = off[val + 1];
-    const BC_GLOBAL uint4* list = entries + (size_t)b * G.n_idx;
-    // blocks before b on which a reference may not equal the capture (it was scored there)
+    const BC_GLOBAL uint4* list = entries + (size_t)b * n_idx;
     for (uint32_t i0 = beg; i0 < end; i0 += 256) {
       uint4 e[4];
       bool on[4];
@@ -93,6 +93,7 @@ __device__ __forceinline__ void wave_seeded_min(const DevGroup& G, uint32_t q1, 
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const uint32_t diff = (q1 ^ e[k].x) | (q2 ^ e[k].y);
+        // a reference that equals the capture on an earlier block was scored there
         bool earlier = false;
         for (uint32_t p = 0; p < b; ++p) earlier = earlier || ((diff >> (p * blen)) & bm) == 0u;
         if (on[k] && !earlier) nearest_add(s, popc(diff), e[k].z, diff == 0u);
@@ -102,7 +103,23 @@ __device__ __forceinline__ void wave_seeded_min(const DevGroup& G, uint32_t q1, 
     // blocks 0..d are done: once the best distance so far is <= b nothing nearer or equally near
     // can still be hiding in the later blocks.
     const uint32_t kmin = wave_min_u32(s.key);
-    if (kmin != 0xFFFFFFFFu && kmin <= b + 1u) break;
+    if (kmin != 0xFFFFFFFFu && kmin <= b + 1u) return true;
+  }
+  return false;
+}
+
+__device__ __forceinline__ void wave_seeded_min(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t& kmin_out,
+                                                bool& unique_out, uint32_t& idx_out) {
+  const uint32_t lane = __lane_id();
+  Nearest s;
+  nearest_init(s);
+  // the coarse index decides whenever some reference is within two mismatches (its three long blocks
+  // make for short buckets); only otherwise is the full one, with its budget + 1 short blocks, walked
+  bool decided = false;
+  if (G.seed2_nb) decided = wave_scan_blocks(G.seed2_nb, G.seed2_blen, G.seed2_off(), G.seed2_list(), G.n_idx, q1, q2, s);
+  if (!decided) {
+    nearest_init(s);  // whatever the coarse pass met is met again
+    wave_scan_blocks(G.seed_nb, G.seed_blen, G.seed_off(), G.seed_list(), G.n_idx, q1, q2, s);
   }
   for (uint32_t i = lane; i < G.n_odd; i += 64) {
     const uint32_t j = G.odd_list()[i];

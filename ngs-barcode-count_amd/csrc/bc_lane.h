@@ -622,33 +622,46 @@ BC_HD uint32_t single_n_lhash(const Quad* __restrict__ area, uint32_t off, uint3
 // the pigeonhole search over all budget+1 blocks has to decide.
 BC_HD void tier_probe(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t& best, uint32_t& cnt, uint32_t& idx) {
   const uint32_t blen = G.tier_blen, bm = (1u << blen) - 1u, nbk = 1u << (2u * blen);
-  const BC_GLOBAL uint32_t* off = G.tier_off();
-  const BC_GLOBAL uint32_t* list = G.tier_list();
-  uint32_t beg[2], end[2];
+  const BC_GLOBAL uint32_t* bkt = G.tier_bkt();
+  // both buckets' heads (a 64-byte line each) are requested before either is looked at: one round trip
+  uint32_t val[2];
+  uint32_t e[2][4][4];
 #pragma unroll
   for (uint32_t b = 0; b < 2; ++b) {
     const uint32_t sh = b * G.tier_stride;
-    const uint32_t val = ((q1 >> sh) & bm) | (((q2 >> sh) & bm) << blen);
-    beg[b] = off[b * (nbk + 1u) + val];
-    end[b] = off[b * (nbk + 1u) + val + 1u];
+    val[b] = ((q1 >> sh) & bm) | (((q2 >> sh) & bm) << blen);
+    const BC_GLOBAL uint32_t* line = bkt + ((size_t)b * nbk + val[b]) * 16u;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k)
+#pragma unroll
+      for (uint32_t c = 0; c < 4; ++c) e[b][k][c] = line[k * 4u + c];
   }
   best = 0xFFFFFFFFu;
   cnt = 0;
   idx = kFail;
+  auto score = [&](uint32_t r1, uint32_t r2, uint32_t j, bool second_block, bool on) {
+    const uint32_t diff = (q1 ^ r1) | (q2 ^ r2);
+    // a reference that equals the capture on block 0 too was met there
+    const bool use = on && !(second_block && (diff & bm) == 0u);
+    const uint32_t d = popc(diff);
+    if (use && d < best) {
+      best = d;
+      cnt = 1;
+      idx = j;
+    } else if (use && d == best) {
+      ++cnt;
+    }
+  };
 #pragma unroll
   for (uint32_t b = 0; b < 2; ++b) {
-    for (uint32_t i = beg[b]; i < end[b]; ++i) {
-      const BC_GLOBAL uint32_t* e = list + ((size_t)b * G.n_idx + i) * 4u;
-      const uint32_t diff = (q1 ^ e[0]) | (q2 ^ e[1]);
-      if (b == 1u && (diff & bm) == 0u) continue;  // equal on block 0 too: met there
-      const uint32_t d = popc(diff);
-      if (d < best) {
-        best = d;
-        cnt = 1;
-        idx = e[2];
-      } else if (d == best) {
-        ++cnt;
-      }
+    const uint32_t n = e[b][0][3];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) score(e[b][k][0], e[b][k][1], e[b][k][2], b == 1u, k < n);
+    if (n > 4u) {  // the rest of a long bucket
+      const BC_GLOBAL uint32_t* off = G.tier_off() + (size_t)b * (nbk + 1u);
+      const BC_GLOBAL uint32_t* list = G.tier_list() + (size_t)b * G.n_idx * 4u;
+      for (uint32_t i = off[val[b]] + 4u, end = off[val[b] + 1u]; i < end; ++i)
+        score(list[i * 4u], list[i * 4u + 1u], list[i * 4u + 2u], b == 1u, true);
     }
   }
 }
@@ -865,7 +878,15 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
                   need_m &= ~(1u << u);
                 }
               }
-              if (clean) {
+              if (clean && G.tier_blen && !(pl.ablate & 0x800u)) {
+                // the one-mismatch tier also finds the capture itself (distance 0): no separate exact lookup
+                bool settled = false;
+                const uint32_t t = tier_lookup(G, q1[u], q2[u], settled);
+                if (settled) {
+                  r[u] = t;
+                  need_m &= ~(1u << u);
+                }
+              } else if (clean) {
                 const uint64_t key = (uint64_t)q1[u] | ((uint64_t)q2[u] << 32);
                 uint32_t h = (uint32_t)hash64(key) & G.hmask;
                 for (;;) {
@@ -877,15 +898,6 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
                     break;
                   }
                   h = (h + 1u) & G.hmask;
-                }
-                // not a reference: is one a single mismatch away?  (each lane searches for itself)
-                if (((need_m >> u) & 1u) && G.tier_blen && !(pl.ablate & 0x800u)) {
-                  bool settled = false;
-                  const uint32_t t = tier_lookup(G, q1[u], q2[u], settled);
-                  if (settled) {
-                    r[u] = t;
-                    need_m &= ~(1u << u);
-                  }
                 }
               }
             } else {

@@ -367,6 +367,27 @@ bool bc_plan::lower(HostDevPlan& out) const {
         G.seed_blen = blen;
         G.n_idx = (uint32_t)plain.size();
         G.n_odd = (uint32_t)H.odd_list.size();
+        // coarser index for up to two mismatches (three blocks), in front of the full one
+        if (nb > 3 && G.len / 3u >= 5u) {
+          const uint32_t b2 = std::min<uint32_t>(8u, G.len / 3u), nbk2 = 1u << (2 * b2), bm2 = (1u << b2) - 1;
+          H.seed2_off.assign((size_t)3 * (nbk2 + 1), 0);
+          H.seed2_list.assign((size_t)3 * plain.size() * 4, 0);
+          for (uint32_t b = 0; b < 3; ++b) {
+            auto value = [&](uint32_t j) { return ((H.r1[j] >> (b * b2)) & bm2) | (((H.r2[j] >> (b * b2)) & bm2) << b2); };
+            uint32_t* off = &H.seed2_off[(size_t)b * (nbk2 + 1)];
+            for (uint32_t j : plain) off[value(j) + 1]++;
+            for (uint32_t v = 0; v < nbk2; ++v) off[v + 1] += off[v];
+            std::vector<uint32_t> cur(off, off + nbk2);
+            for (uint32_t j : plain) {
+              uint32_t* e = &H.seed2_list[((size_t)b * plain.size() + cur[value(j)]++) * 4];
+              e[0] = H.r1[j];
+              e[1] = H.r2[j];
+              e[2] = j;
+            }
+          }
+          G.seed2_nb = 3;
+          G.seed2_blen = b2;
+        }
         // first tier (see bc_device_plan.h): two blocks, one per half of the barcode
         const uint32_t tb = std::min<uint32_t>(8u, G.len / 2u);
         if (G.max_err >= 1 && tb >= 4 && H.odd_list.empty()) {
@@ -385,6 +406,24 @@ bool bc_plan::lower(HostDevPlan& out) const {
               e[0] = H.r1[j];
               e[1] = H.r2[j];
               e[2] = j;
+            }
+          }
+          // the head of every bucket, laid out so that a lookup is one 64-byte line
+          H.tier_bkt.assign((size_t)2 * tnbk * 16, 0);
+          for (uint32_t b = 0; b < 2; ++b) {
+            const uint32_t* off = &H.tier_off[(size_t)b * (tnbk + 1)];
+            for (uint32_t v = 0; v < tnbk; ++v) {
+              const uint32_t n = off[v + 1] - off[v];
+              uint32_t* line = &H.tier_bkt[((size_t)b * tnbk + v) * 16];
+              for (uint32_t k = 0; k < 4; ++k) {
+                if (k < n) {
+                  const uint32_t* e = &H.tier_list[((size_t)b * plain.size() + off[v] + k) * 4];
+                  line[k * 4 + 0] = e[0];
+                  line[k * 4 + 1] = e[1];
+                  line[k * 4 + 2] = e[2];
+                }
+                line[k * 4 + 3] = n;
+              }
             }
           }
           G.tier_blen = tb;

@@ -52,7 +52,7 @@ struct HostSet {
   std::vector<uint8_t> rlen;
   std::vector<uint64_t> hkeys;
   std::vector<uint32_t> hvals;
-  std::vector<uint32_t> seed_off, seed_list, odd_list, tier_off, tier_list;
+  std::vector<uint32_t> seed_off, seed_list, odd_list, tier_off, tier_list, tier_bkt, seed2_off, seed2_list;
 };
 
 struct HostDevPlan {

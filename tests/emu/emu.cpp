@@ -92,6 +92,7 @@ void* emu_plan_create(const bc_plan* p) {
     G.hvals_a = (uint64_t)(uintptr_t)H.hvals.data();
     G.tier_off_a = (uint64_t)(uintptr_t)H.tier_off.data();
     G.tier_list_a = (uint64_t)(uintptr_t)H.tier_list.data();
+    G.tier_bkt_a = (uint64_t)(uintptr_t)H.tier_bkt.data();
     if (G.mode == bc::kSetDirect) {
       const uint32_t nq = 1u << (2 * G.len);
       E->dtables[g].resize(nq);
