@@ -33,6 +33,10 @@ import ngs_barcode_count_amd as pkg
 from ngs_barcode_count_amd import distributed as bcdist
 import workloads
 
+# the specialised kernel is normally precompiled by build(); should the cache miss, compile it during the
+# (untimed) warm-up rather than on a worker thread part-way through the timed steps
+os.environ.setdefault("BC_JIT", "force")
+
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); a device copy reaches ~5-6.3 TB/s depending on the box
 DEFAULT_READS = {"config2": 10_000_000, "config3": 100_000_000, "config4": 50_000_000, "config5": 20_000_000}
 WORKLOAD_TEXT = {
