@@ -937,6 +937,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
       }
       pend_n &= pend_n - 1u;
     }
+    if (pl.ablate & 0x1000u) gather_m = 0;  // perf experiment: what the table round trip costs
     // correction-table gathers of the captures LDS did not answer: all lanes load (the idle ones entry
     // 0, one shared cache line), so the four loads are in flight together
     uint32_t tv[4];

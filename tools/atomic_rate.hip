@@ -20,6 +20,21 @@ __global__ void scatter_add(uint32_t* table, uint64_t range, uint32_t per, uint6
   }
 }
 
+// the same with an explicit cache policy on the atomic instruction
+template <int kPolicy>
+__global__ void scatter_add_policy(uint32_t* table, uint64_t range, uint32_t per, uint64_t seed) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (uint32_t i = 0; i < per; ++i) {
+    const uint64_t h = mix(seed + t * per + i);
+    uint32_t* p = &table[h % range];
+    const uint32_t one = 1u;
+    if (kPolicy == 0) asm volatile("global_atomic_add %0, %1, off" ::"v"(p), "v"(one) : "memory");
+    if (kPolicy == 1) asm volatile("global_atomic_add %0, %1, off nt" ::"v"(p), "v"(one) : "memory");
+    if (kPolicy == 2) asm volatile("global_atomic_add %0, %1, off sc1" ::"v"(p), "v"(one) : "memory");
+    if (kPolicy == 3) asm volatile("global_atomic_add %0, %1, off sc1 nt" ::"v"(p), "v"(one) : "memory");
+  }
+}
+
 // same address stream, plain loads (what a gather of that locality costs)
 __global__ void scatter_load(const uint32_t* table, uint64_t range, uint32_t per, uint64_t seed, uint32_t* sink) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -54,7 +69,22 @@ int main() {
       hipEventSynchronize(e1);
       hipEventElapsedTime(&ms_l, e0, e1);
     }
-    printf("range %8.0f MiB  atomics %7.2f G/s   loads %7.2f G/s\n", r * 4.0 / (1 << 20), n / ms_a / 1e6, n / ms_l / 1e6);
+    float ms_p[4] = {0, 0, 0, 0};
+    for (int pol = 0; pol < 4; ++pol) {
+      for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0);
+        if (pol == 0) hipLaunchKernelGGL(scatter_add_policy<0>, dim3(blocks), dim3(threads), 0, 0, table, r, per, 777ull + rep);
+        if (pol == 1) hipLaunchKernelGGL(scatter_add_policy<1>, dim3(blocks), dim3(threads), 0, 0, table, r, per, 777ull + rep);
+        if (pol == 2) hipLaunchKernelGGL(scatter_add_policy<2>, dim3(blocks), dim3(threads), 0, 0, table, r, per, 777ull + rep);
+        if (pol == 3) hipLaunchKernelGGL(scatter_add_policy<3>, dim3(blocks), dim3(threads), 0, 0, table, r, per, 777ull + rep);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms_p[pol], e0, e1);
+      }
+    }
+    printf("range %8.0f MiB  atomics %7.2f G/s   loads %7.2f G/s   asm: plain %6.2f  nt %6.2f  sc1 %6.2f  sc1+nt %6.2f G/s\n",
+           r * 4.0 / (1 << 20), n / ms_a / 1e6, n / ms_l / 1e6, n / ms_p[0] / 1e6, n / ms_p[1] / 1e6, n / ms_p[2] / 1e6,
+           n / ms_p[3] / 1e6);
     fflush(stdout);
   }
   return 0;
