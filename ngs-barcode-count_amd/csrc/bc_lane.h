@@ -814,6 +814,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
   shr_lane<NW>(P.pn, start);
   if (anyx) shr_lane<NW>(P.px, start);
   uint64_t didx = 0;
+  bool raw_foreign = false;
   const bool located = active && outcome == kMatched;  // anchored; the quality verdict is still to come
   const uint32_t ng = (pl.ablate & 0x20u) ? 0u : pl.n_groups;
   // four groups at a time: first every capture is cut out and looked up (LDS, then the table gathers
@@ -1005,13 +1006,15 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
           }
         } else if (pre_ok && outcome == kMatched) {
           // no known set: the capture is taken as it is (parse.rs:453-454, 487)
-          if (qx[u]) unsupported = true;  // a byte outside ACGTN has no code
+          if (qx[u]) raw_foreign = true;  // a byte outside ACGTN has no code -- matters only if the read ends up counted
           didx += base5_code(q1[u], q2[u], qn[u], G.len) * G.table_stride;
         }
       }
     }
   }
   if (!quality_done) quality_filter(0u);  // a scheme without barcode groups
+  // a later group may still have failed the read: then that failure is the outcome, as in the reference
+  if (raw_foreign && outcome == kMatched) unsupported = true;
   ops.groups_done();
   // ---- random barcode: kept as captured, never corrected (parse.rs:510-516) ------------------
   if (pl.has_random) {

@@ -158,3 +158,82 @@ RANDOM_CASES = ["del_random", "example_files", "example_files_samples", "example
                 "raw_all_random"]
 NO_RANDOM_CASES = [c for c in ALL_CASES if c not in RANDOM_CASES]
 RANDOM_ENGINE_CASES = list(RANDOM_CASES)
+
+
+def random_case(seed, n=300):
+    """A randomly drawn scheme (constants with the odd N, optional sample group, 1-4 counted groups of 3-20
+    bases), random set sizes / budgets / quality threshold, conversion files present or not: the shapes the
+    hand-written cases above do not reach.  No random barcode (set semantics are covered there)."""
+    rng = np.random.default_rng(90000 + seed)
+    c = dict(name="random_%d" % seed, kwargs={})
+
+    def const(lo, hi):
+        k = int(rng.integers(lo, hi + 1))
+        t = readgen.rand_seq(rng, k)
+        if rng.random() < 0.25 and k >= 5:  # a scheme N or two inside the constant
+            t = list(t)
+            for _ in range(int(rng.integers(1, 3))):
+                t[int(rng.integers(1, k - 1))] = "N"
+            t = "".join(t)
+        return t
+
+    parts, sample_len, group_lens = [], None, []
+    if rng.random() < 0.3:
+        parts.append(const(3, 12))
+    if rng.random() < 0.6:
+        sample_len = int(rng.integers(4, 11))
+        parts.append("[%d]" % sample_len)
+    parts.append(const(4, 20))
+    for g in range(int(rng.integers(1, 5))):
+        r = rng.random()
+        k = int(rng.integers(3, 11)) if r < 0.75 else (int(rng.integers(11, 16)) if r < 0.9 else int(rng.integers(16, 21)))
+        group_lens.append(k)
+        parts.append("{%d}" % k)
+        parts.append(const(2, 14))
+    scheme = "".join(parts)
+    if rng.random() < 0.3:
+        scheme = scheme.replace("{", "\n{").replace("}", "}\n")  # the multi-line form of the format file
+    c["scheme"] = scheme
+    L = len(scheme.replace("\n", "").replace("[", "").replace("]", "").replace("{", "").replace("}", ""))
+    L = sum(v if k != "C" else len(v) for k, v in readgen.scheme_layout(scheme))
+    # known sets, small enough that the dense table stays below ~4 M entries
+    budget = 4_000_000
+    samples = None
+    if sample_len is not None:
+        ns = int(rng.integers(2, 9))
+        samples = readgen.make_set(rng, ns, sample_len, int(rng.integers(1, 4)) if sample_len >= 6 else 1)
+        budget //= ns
+    counted = []
+    for k in group_lens:
+        cap = max(2, min(4 ** k // 4, int(budget ** (1.0 / max(len(group_lens) - len(counted), 1)))))
+        hi = min(cap, 300 if k >= 16 else 120)
+        m = int(rng.integers(2, hi + 1))
+        counted.append(readgen.make_set(rng, m, k, 1 if k < 5 else int(rng.integers(1, 3))))
+        budget = max(budget // m, 2)
+    have_sample_file = samples is not None and rng.random() < 0.8
+    have_counted_file = rng.random() < 0.8
+    # raw captures must fit a 64-bit mixed-radix key: keep it dense unless the groups are short
+    raw_bits = (0 if have_sample_file or samples is None else sample_len) + (0 if have_counted_file else sum(group_lens))
+    if raw_bits > 24:
+        have_sample_file, have_counted_file = samples is not None, True
+    c["samples"] = {x: "S%d" % i for i, x in enumerate(samples)} if have_sample_file else None
+    c["counted"] = counted if have_counted_file else None
+    kw = {}
+    if rng.random() < 0.4:
+        kw["max_barcode"] = int(rng.integers(0, 3))
+    if rng.random() < 0.4 and samples is not None:
+        kw["max_sample"] = int(rng.integers(0, 3))
+    if rng.random() < 0.4:
+        kw["max_constant"] = int(rng.integers(0, 6))
+    if rng.random() < 0.5:
+        kw["min_quality"] = float(rng.integers(10, 31)) + (0.5 if rng.random() < 0.3 else 0.0)
+    c["kwargs"] = kw
+    read_len = min(128, L + int(rng.integers(0, 45)))
+    # a raw capture holding a byte outside ACGTN is the engine's one documented refusal (BC_UNSUPPORTED_READS;
+    # the reference would count it under the literal string): such bytes only where every group has a file
+    raw_mode = (samples is not None and not have_sample_file) or not have_counted_file
+    p_other = 0.0 if raw_mode else float(rng.choice([0.0, 0.0, 0.002]))
+    c["reads"] = readgen.gen_reads(rng, scheme, n, read_len, samples, counted, p_sub=float(rng.choice([0.0, 0.01, 0.03, 0.06])),
+                                   p_n=float(rng.choice([0.0, 0.003, 0.02])), p_other=p_other,
+                                   var_len=bool(rng.random() < 0.5))
+    return c

@@ -138,6 +138,25 @@ def test_random_barcode_engine_vs_oracle(name, kernel):
     eng2.close()
 
 
+@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("kernel", ["generic", "specialised"], indirect=True)
+def test_randomly_drawn_schemes(seed, kernel):
+    """schemes, sets, budgets and thresholds drawn at random (cases.random_case), both kernels vs the oracle"""
+    c = cases.random_case(seed, n=2000)
+    plan = make_plan(c)
+    seq, qual, lens = readgen.to_arrays(c["reads"])
+    stride = seq.shape[1]
+    eng, outc, idx = run_device(plan, seq, qual, lens, stride, stride)
+    discard = (not plan.sample_barcode) and len(plan.samples()) > 0
+    o = parity.check_per_read(c, plan, outc, idx, discard)
+    got = eng.counters()
+    for k, v in o.counters.items():
+        assert got[k] == v, (k, got, o.counters)
+    assert eng.result_rows() == o.rows()
+    check_kernel(eng, kernel)
+    eng.close()
+
+
 @pytest.mark.parametrize("name", ["raw_counted", "raw_sample"])
 def test_count_map_export_import_merges_shards(name):
     """raw-key plans across GPUs: two engines count one half of the reads each; adding the second one's

@@ -29,6 +29,17 @@ def test_lane_code_vs_oracle(name, use_lens):
     parity.check_per_read(c, plan, outc, idx, discard)
 
 
+@pytest.mark.parametrize("seed", range(40))
+def test_randomly_drawn_schemes(seed):
+    """schemes, sets, budgets and thresholds drawn at random (cases.random_case): lane code vs oracle"""
+    c = cases.random_case(seed, n=300)
+    plan = emu_lib.make_plan(c)
+    seq, qual, lens = readgen.to_arrays(c["reads"])
+    stride = seq.shape[1]
+    outc, idx, entries, discard = emu_lib.emulate(plan, seq.reshape(-1), qual.reshape(-1), lens, stride, stride)
+    parity.check_per_read(c, plan, outc, idx, discard)
+
+
 @pytest.mark.parametrize("name", cases.RANDOM_ENGINE_CASES)
 def test_random_barcode_keys_vs_oracle(name):
     """random-barcode schemes: the lane code's (tuple, random) key + set semantics vs the oracle's
@@ -110,3 +121,26 @@ def test_single_n_captures(seed):
     outc, idx, entries, discard = emu_lib.emulate(plan, seq.reshape(-1), qual.reshape(-1), None, 100, 100)
     parity.check_per_read(c, plan, outc, idx, discard)
     assert 0 < int((outc == 0).sum()) < len(outc)
+
+
+def test_foreign_byte_in_a_raw_capture_only_matters_for_counted_reads():
+    """A raw (file-less) sample capture holding a byte outside ACGTN cannot be coded into the key; the engine
+    refuses such a read (BC_UNSUPPORTED_READS) -- but only if it would have been counted: when a later group
+    fails, that failure is the outcome, exactly as in the reference (parse.rs:453-454, 487-505)."""
+    import numpy as np
+    c = dict(name="raw_foreign", scheme="[6]ACGTACGGT{6}TTGGCCAA", samples=None, counted=[["AACCGG", "TTGGAA"]],
+             kwargs=dict(max_barcode=0), reads=[])
+    q = "I" * 40
+    good = "GATTxC" + "ACGTACGGT" + "AACCGG" + "TTGGCCAA"
+    bad = "GATTxC" + "ACGTACGGT" + "ACACAC" + "TTGGCCAA"
+    clean = "GATTAC" + "ACGTACGGT" + "TTGGAA" + "TTGGCCAA"
+    for s in (good, bad, clean):
+        s = (s + "ACGT" * 10)[:40]
+        c["reads"].append((s, q))
+    plan = emu_lib.make_plan(c)
+    seq, qual, lens = readgen.to_arrays(c["reads"])
+    outc, idx, entries, discard = emu_lib.emulate(plan, seq.reshape(-1), qual.reshape(-1), lens, 40, 40)
+    o = parity.oracle_for(c)
+    exp = [o.process(s, qq) for s, qq in c["reads"]]
+    assert exp == ["matched", "barcode", "matched"]
+    assert [int(v) for v in outc] == [7, parity.CODE["barcode"], parity.CODE["matched"]]

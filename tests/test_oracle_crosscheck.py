@@ -27,6 +27,20 @@ def test_oracle_vs_pyref(name):
     assert len(outcomes) >= 2
 
 
+@pytest.mark.parametrize("seed", range(40))
+def test_oracle_vs_pyref_on_randomly_drawn_schemes(seed):
+    """the two independent restatements (C, string level; Python, the reference's regex through `re`) on schemes
+    neither was written against"""
+    c = cases.random_case(seed, n=300)
+    kw = c["kwargs"]
+    o = oracle_lib.Oracle(c["scheme"], samples=c["samples"], counted=c["counted"], **kw)
+    p = pyref.Parser(c["scheme"], samples=c["samples"], counted=c["counted"], **kw)
+    for seq, qual in c["reads"]:
+        assert o.process(seq, qual) == p.process(seq, qual), (seq, qual)
+    assert o.counters == p.counters
+    assert o.rows() == p.rows()
+
+
 def test_scheme_quirks_agree():
     for text in ["[4]ACGT{3}", "# c\n{5}\nacgt\n(3)\n", "ACGTNNAC{4}NTT", "nnACGT{3}", "AC GT{2}x[3]", "{3}{4}AC",
                  "ACGT\r\n{3}\r\n"]:
