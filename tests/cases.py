@@ -14,6 +14,8 @@ GAP_SCHEME = "[32]AC{32}GT{8}ACGGT"  # first constant at position 32 and 34-base
 
 def build_case(name, seed=0, n=600):
     """-> dict(scheme, samples {seq:id} | None, counted [list of seqs] | None, kwargs, reads)"""
+    if name.startswith("rnd_rb_"):
+        return random_case(int(name[7:]) + 7 * seed, n, with_random=True)
     rng = np.random.default_rng(seed + 1000 * (abs(hash(name)) % 1000 if False else sum(map(ord, name))))
     c = dict(name=name, kwargs={})
     if name == "del_exact":
@@ -157,10 +159,10 @@ ALL_CASES = ["del_exact", "del_mismatch_quality", "del_dense_ties", "del_random"
 RANDOM_CASES = ["del_random", "example_files", "example_files_samples", "example_files_random_nosample",
                 "raw_all_random"]
 NO_RANDOM_CASES = [c for c in ALL_CASES if c not in RANDOM_CASES]
-RANDOM_ENGINE_CASES = list(RANDOM_CASES)
+RANDOM_ENGINE_CASES = list(RANDOM_CASES) + ["rnd_rb_%d" % i for i in range(8)]
 
 
-def random_case(seed, n=300):
+def random_case(seed, n=300, with_random=False):
     """A randomly drawn scheme (constants with the odd N, optional sample group, 1-4 counted groups of 3-20
     bases), random set sizes / budgets / quality threshold, conversion files present or not: the shapes the
     hand-written cases above do not reach.  No random barcode (set semantics are covered there)."""
@@ -190,6 +192,12 @@ def random_case(seed, n=300):
         group_lens.append(k)
         parts.append("{%d}" % k)
         parts.append(const(2, 14))
+    random_len = 0
+    if with_random:  # a random (UMI) barcode somewhere behind the first counted group
+        random_len = int(rng.integers(5, 13))
+        parts.insert(int(rng.integers(parts.index("{%d}" % group_lens[0]) + 1, len(parts) + 1)), "(%d)" % random_len)
+        if parts[-1].startswith("("):
+            parts.append(const(2, 6))
     scheme = "".join(parts)
     if rng.random() < 0.3:
         scheme = scheme.replace("{", "\n{").replace("}", "}\n")  # the multi-line form of the format file
@@ -214,7 +222,7 @@ def random_case(seed, n=300):
     have_counted_file = rng.random() < 0.8
     # raw captures must fit a 64-bit mixed-radix key: keep it dense unless the groups are short
     raw_bits = (0 if have_sample_file or samples is None else sample_len) + (0 if have_counted_file else sum(group_lens))
-    if raw_bits > 24:
+    if raw_bits > 24 or with_random:  # (raw captures + random barcode: the fixed case raw_all_random)
         have_sample_file, have_counted_file = samples is not None, True
     c["samples"] = {x: "S%d" % i for i, x in enumerate(samples)} if have_sample_file else None
     c["counted"] = counted if have_counted_file else None
@@ -232,8 +240,8 @@ def random_case(seed, n=300):
     # a raw capture holding a byte outside ACGTN is the engine's one documented refusal (BC_UNSUPPORTED_READS;
     # the reference would count it under the literal string): such bytes only where every group has a file
     raw_mode = (samples is not None and not have_sample_file) or not have_counted_file
-    p_other = 0.0 if raw_mode else float(rng.choice([0.0, 0.0, 0.002]))
+    p_other = 0.0 if (raw_mode or with_random) else float(rng.choice([0.0, 0.0, 0.002]))  # (the same goes for a random barcode)
     c["reads"] = readgen.gen_reads(rng, scheme, n, read_len, samples, counted, p_sub=float(rng.choice([0.0, 0.01, 0.03, 0.06])),
                                    p_n=float(rng.choice([0.0, 0.003, 0.02])), p_other=p_other,
-                                   var_len=bool(rng.random() < 0.5))
+                                   var_len=bool(rng.random() < 0.5), dup_frac=0.35 if with_random else 0.0)
     return c
