@@ -123,6 +123,12 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if world > 1:
+        # warm-up of the end-of-job exchange too: RCCL sets up its peer-to-peer connections on first use
+        if random_mode:
+            bcdist.exchange_keys(torch.arange(world * 64, dtype=torch.int64, device=dev))
+        else:
+            bcdist.reduce_table(torch.ones(world * 4096, dtype=torch.int32, device=dev), dst=0)
     barrier()
     eng.reset()
     eng.timing(True)
