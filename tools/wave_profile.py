@@ -10,7 +10,7 @@ import workloads
 
 name = sys.argv[1] if len(sys.argv) > 1 else "config3"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20_000_000
-w = workloads.make(name)
+w = workloads.make(name, read_len=int(sys.argv[3]) if len(sys.argv) > 3 else 100)
 R = w.read_len
 dseq = torch.empty(n * R, dtype=torch.uint8, device="cuda")
 dqual = torch.empty(n * R, dtype=torch.uint8, device="cuda")
