@@ -36,9 +36,8 @@ def reduce_table(table, dst=0, method=None):
     mine = n // world
     recv = torch.empty(n, dtype=table.dtype, device=table.device)
     dist.all_to_all_single(recv, table)
-    part = recv[:mine]
-    for r in range(1, world):  # in-place 32-bit adds: wrap like the u32 counters they are
-        part += recv[r * mine:(r + 1) * mine]
+    # one pass over what arrived; 32-bit accumulation wraps like the u32 counters these are
+    part = torch.sum(recv.view(world, mine), dim=0, dtype=table.dtype)
     if rank == dst:
         table[dst * mine:(dst + 1) * mine].copy_(part)
         ops = [dist.P2POp(dist.irecv, table[r * mine:(r + 1) * mine], r) for r in range(world) if r != dst]
