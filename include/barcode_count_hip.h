@@ -170,6 +170,17 @@ int bc_engine_clear_keys(bc_engine *e);
 int bc_engine_export_counts(bc_engine *e, void *d_keys, void *d_counts, uint64_t capacity, uint64_t *n);
 int bc_engine_import_counts(bc_engine *e, const void *d_keys, const void *d_counts, uint64_t n);
 
+/* Dense counts for the wire.  out[i] = table[i] where that fits a byte, else 0 with (i, table[i]) appended to the
+ * overflow list; *n_ovf = entries the list needs (call again with a larger one if it exceeds ovf_capacity).  The
+ * receiver adds the bytes up and then the list entries -- exact for any counts, a quarter of the bytes when counts
+ * are small (ngs-barcode-count_amd/distributed.py reduce_table).  Device pointers; runs on hip_stream and waits. */
+int bc_table_pack_u8(const void *d_table_u32, uint64_t n, void *d_out_u8, void *d_ovf_idx_u64, void *d_ovf_val_u32,
+                     uint64_t ovf_capacity, uint64_t *n_ovf, int device_id, void *hip_stream);
+
+/* ... and the receiving side of the exchange: out[i] = sum of the n_rows byte slices rows[r * n + i], i < n
+ * (n a multiple of 4). */
+int bc_table_sum_u8(const void *d_rows_u8, uint32_t n_rows, uint64_t n, void *d_out_u32, int device_id, void *hip_stream);
+
 /* Debug / parity-test hook: the next submits also write, for read i of the submit, its outcome
  * (BC_* counter index; BC_MATCHED = passed every test) to d_outcome_u8[i] and its dense table index
  * to d_index_u64[i].  Both device pointers; NULL switches tracing off. */

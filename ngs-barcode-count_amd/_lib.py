@@ -72,6 +72,8 @@ ENGINE_API = {
     "bc_engine_rows": (_int, [_vp, _u64, _u64, _vp, _vp, _vp]),
     "bc_engine_timing": (_int, [_vp, _int]),
     "bc_engine_kernel_ms": (_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "bc_table_pack_u8": (_int, [_vp, _u64, _vp, _vp, _vp, _u64, C.POINTER(_u64), _int, _vp]),
+    "bc_table_sum_u8": (_int, [_vp, _u32, _u64, _vp, _int, _vp]),
     "bc_engine_kernel_name": (_cp, [_vp]),
     "bc_engine_sclk_mhz": (_int, [_vp, C.POINTER(C.c_double)]),
     "bc_plan_precompile": (_int, [_vp, _int, _int, _int, _cp]),  # lives with the engine: it drives the device compiler

@@ -15,14 +15,57 @@ def shard(n_total, rank, world):
     return first, base + (1 if rank < extra else 0)
 
 
+def pack_table(table):
+    """dense int32 (u32 bits) counts -> (uint8 tensor, overflow indices int64, overflow values int32):
+    byte[i] = count where it fits a byte, else 0 and (i, count) in the overflow list.  On a GPU tensor this is
+    the engine's bc_table_pack_u8 kernel; on a CPU tensor (the gloo tests) the same thing in torch."""
+    n = table.numel()
+    if table.is_cuda:
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        out = torch.empty(n, dtype=torch.uint8, device=table.device)
+        cap = max(1024, n // 4096)
+        stream = torch.cuda.current_stream(table.device).cuda_stream
+        while True:
+            idx = torch.empty(cap, dtype=torch.int64, device=table.device)
+            val = torch.empty(cap, dtype=torch.int32, device=table.device)
+            need = C.c_uint64()
+            rc = lib.bc_table_pack_u8(table.data_ptr(), n, out.data_ptr(), idx.data_ptr(), val.data_ptr(), cap,
+                                      C.byref(need), table.device.index or 0, stream)
+            if rc != 0:
+                raise RuntimeError(_lib.last_error(lib))
+            if need.value <= cap:
+                return out, idx[:need.value], val[:need.value]
+            cap = need.value
+    big = (table < 0) | (table > 255)
+    idx = torch.nonzero(big).flatten()
+    return torch.where(big, torch.zeros_like(table), table).to(torch.uint8), idx, table[idx]
+
+
+def sum_slices(rows, world, mine, dtype):
+    """rows: uint8 tensor of world slices of `mine` bytes -> their element-wise sum as `dtype`"""
+    if rows.is_cuda and mine % 4 == 0:
+        from . import _lib
+        lib = _lib.load()
+        out = torch.empty(mine, dtype=dtype, device=rows.device)
+        rc = lib.bc_table_sum_u8(rows.data_ptr(), world, mine, out.data_ptr(), rows.device.index or 0,
+                                 torch.cuda.current_stream(rows.device).cuda_stream)
+        if rc != 0:
+            raise RuntimeError(_lib.last_error(lib))
+        return out
+    return torch.sum(rows.view(world, mine), dim=0, dtype=dtype)
+
+
 def reduce_table(table, dst=0, method=None):
     """Sum of every rank's dense u32 counter table (viewed as int32: same bits) onto rank dst, in place
-    there.  On xGMI every GPU has its own link to every other, so the default is not a ring:
-      1. all-to-all (equal slices): rank r receives slice r of every table, 7 peers at once, one link each,
-      2. each rank adds up the slices it received (local, HBM speed),
-      3. the summed slices are sent to dst point to point, again one link each.
-    A ring reduce would push the whole 16 GB table of the DEL workloads through one link's bandwidth.
-    Tables whose length is not a multiple of the world size, and method="reduce" /
+    there.  On xGMI every GPU has its own link to every other, so the default is not a ring, and the
+    counts travel as bytes (pack_table: exact, the rare count above 255 goes in a side list):
+      1. all-to-all (equal slices): rank r receives slice r of every packed table, 7 peers at once,
+      2. each rank adds up the slices it received, plus the overflow entries sent to it (local, HBM speed),
+      3. the summed slices are packed again and sent to dst point to point, one link each.
+    A ring reduce of the raw table would push 16 GB (DEL workloads) through one link's bandwidth.
+    Tables whose length is not a multiple of 4 x the world size, and method="reduce" /
     BC_TABLE_REDUCE=reduce, use torch.distributed.reduce."""
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return table
@@ -30,22 +73,57 @@ def reduce_table(table, dst=0, method=None):
     world, rank = dist.get_world_size(), dist.get_rank()
     method = method or os.environ.get("BC_TABLE_REDUCE", "alltoall")
     n = table.numel()
-    if method == "reduce" or n % world or n == 0:
+    if method == "reduce" or n % (4 * world) or n == 0:
         dist.reduce(table, dst=dst, op=dist.ReduceOp.SUM)
         return table
     mine = n // world
-    recv = torch.empty(n, dtype=table.dtype, device=table.device)
-    dist.all_to_all_single(recv, table)
-    # one pass over what arrived; 32-bit accumulation wraps like the u32 counters these are
-    part = torch.sum(recv.view(world, mine), dim=0, dtype=table.dtype)
+    dev = table.device
+    # 1. packed slices to their owners (+ the overflow entries, addressed by slice)
+    small, oidx, oval = pack_table(table)
+    recv = torch.empty(n, dtype=torch.uint8, device=dev)
+    dist.all_to_all_single(recv, small)
+    del small
+    ridx, rval = _exchange_by_owner(oidx, oval, oidx // mine, world)
+    # 2. one pass over what arrived
+    part = sum_slices(recv, world, mine, table.dtype)
+    del recv
+    if ridx.numel():
+        part.index_add_(0, ridx - rank * mine, rval)
+    # 3. summed slices to dst, packed again
+    small, oidx, oval = pack_table(part)
     if rank == dst:
-        table[dst * mine:(dst + 1) * mine].copy_(part)
-        ops = [dist.P2POp(dist.irecv, table[r * mine:(r + 1) * mine], r) for r in range(world) if r != dst]
+        got = torch.empty(n, dtype=torch.uint8, device=dev)
+        got[dst * mine:(dst + 1) * mine].copy_(small)
+        ops = [dist.P2POp(dist.irecv, got[r * mine:(r + 1) * mine], r) for r in range(world) if r != dst]
     else:
-        ops = [dist.P2POp(dist.isend, part, dst)]
+        ops = [dist.P2POp(dist.isend, small, dst)]
     for req in dist.batch_isend_irecv(ops):
         req.wait()
+    gidx, gval = _exchange_by_owner(oidx + rank * mine, oval, torch.full_like(oidx, dst), world)
+    if rank == dst:
+        table.copy_(got)  # uint8 -> int32
+        if gidx.numel():
+            table.index_add_(0, gidx, gval)  # the bytes there are 0
     return table
+
+
+def _exchange_by_owner(idx, val, owner, world):
+    """(int64 idx, int32 val) pairs -> the rank named by `owner` (all-to-all with uneven splits)"""
+    any_pairs = torch.tensor([idx.numel()], dtype=torch.int64, device=idx.device)
+    dist.all_reduce(any_pairs, op=dist.ReduceOp.MAX)
+    if int(any_pairs.item()) == 0:  # the usual case: every count fitted its byte, nothing to exchange
+        return idx[:0], val[:0]
+    order = torch.argsort(owner)
+    idx, val = idx[order].contiguous(), val[order].contiguous()
+    send = torch.bincount(owner, minlength=world).to(torch.int64)
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send)
+    n_recv = int(recv.sum().item())
+    out_i = torch.empty(n_recv, dtype=torch.int64, device=idx.device)
+    out_v = torch.empty(n_recv, dtype=val.dtype, device=val.device)
+    dist.all_to_all_single(out_i, idx, recv.tolist(), send.tolist())
+    dist.all_to_all_single(out_v, val, recv.tolist(), send.tolist())
+    return out_i, out_v
 
 
 def reduce_counters(counters, device, dst=0):

@@ -201,10 +201,12 @@ def _worker_table(rank, world, port, out_path):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ok = True
-    for n in (6, 7, 600, 4098, 4099):  # multiples of the world size take the all-to-all path, the others the fallback
+    for n in (24, 7, 2400, 4099, 24000):  # multiples of 4 x world take the packed all-to-all path, the others the fallback
         for dst in range(world):
             rng = np.random.default_rng(1000 * rank + n)
-            mine = torch.from_numpy(rng.integers(0, 2**31 - 1, size=n).astype(np.int32))
+            # mostly small counts (one byte on the wire), some large, some with the top bit set (u32 viewed as int32)
+            mine = torch.from_numpy(np.where(rng.random(n) < 0.9, rng.integers(0, 200, size=n),
+                                             rng.integers(-2**31, 2**31 - 1, size=n)).astype(np.int32))
             a, b = mine.clone(), mine.clone()
             bcdist.reduce_table(a, dst=dst, method="alltoall")
             bcdist.reduce_table(b, dst=dst, method="reduce")

@@ -273,3 +273,27 @@ def test_errors_are_loud():
     with pytest.raises(pkg.BarcodeCountError):  # no such device
         pkg.Engine(p, device=99)
     e.close()
+
+
+def test_table_pack_kernel_matches_its_torch_form():
+    """bc_table_pack_u8 (what dense tables travel as between GPUs) against the torch statement of it"""
+    import torch
+    from ngs_barcode_count_amd import distributed as bcdist
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for n in (1, 3, 4, 1001, 1 << 20):
+        small = torch.randint(0, 256, (n,), generator=g, dtype=torch.int32)
+        large = torch.randint(-2**31, 2**31 - 1, (n,), generator=g, dtype=torch.int32)
+        t = torch.where(torch.rand(n, generator=g) < 0.97, small, large)
+        b_cpu, i_cpu, v_cpu = bcdist.pack_table(t)
+        b_gpu, i_gpu, v_gpu = bcdist.pack_table(t.cuda())
+        assert torch.equal(b_cpu, b_gpu.cpu())
+        order = torch.argsort(i_gpu.cpu())  # the kernel appends in no particular order
+        assert torch.equal(i_cpu, i_gpu.cpu()[order]) and torch.equal(v_cpu, v_gpu.cpu()[order])
+        if n % 4 == 0 and n >= 8:
+            w = 4 if n % 16 == 0 else 1
+            assert torch.equal(bcdist.sum_slices(b_gpu, w, n // w, torch.int32).cpu(),
+                               torch.sum(b_cpu.view(w, n // w), dim=0, dtype=torch.int32))
+        # and unpacking restores the table
+        back = b_gpu.to(torch.int32)
+        back.index_add_(0, i_gpu, v_gpu)
+        assert torch.equal(back.cpu(), t)
