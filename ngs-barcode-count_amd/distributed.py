@@ -76,6 +76,16 @@ def reduce_table(table, dst=0, method=None):
     if method == "reduce" or n % (4 * world) or n == 0:
         dist.reduce(table, dst=dst, op=dist.ReduceOp.SUM)
         return table
+    try:
+        return _reduce_table_packed(table, dst, world, rank, n)
+    except RuntimeError as err:  # a backend without one of the collectives used: same error on every rank
+        import sys
+        print("[barcode-count] packed table exchange unavailable (%s); using torch.distributed.reduce" % err, file=sys.stderr)
+        dist.reduce(table, dst=dst, op=dist.ReduceOp.SUM)
+        return table
+
+
+def _reduce_table_packed(table, dst, world, rank, n):
     mine = n // world
     dev = table.device
     # 1. packed slices to their owners (+ the overflow entries, addressed by slice)
