@@ -227,6 +227,11 @@ __device__ __forceinline__ uint64_t map_slot(unsigned long long* __restrict__ sl
   }
 }
 
+// cache policy of the streaming tile fetch: 2 = nt (non-temporal).  Every byte of a batch is read exactly once, so
+// it should not push the correction tables out of L2 or claim Infinity Cache lines; measured 2.3 % on config 3.
+#ifndef BC_DMA_CPOL
+#define BC_DMA_CPOL 2
+#endif
 // Asynchronous tile fetch: global -> LDS without passing through registers
 // (global_load_lds_dwordx4: every lane moves 16 bytes, the wave 1 KiB per instruction, destination
 // = wave-uniform LDS base + lane * 16).  `bytes` must be a multiple of 16 (a full 64-read tile is).
@@ -235,7 +240,7 @@ __device__ __forceinline__ void dma_tile(uint8_t* lds_dst, const uint8_t* __rest
     const uint32_t off = off0 + lane * 16u;
     if (off < bytes)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off),
-                                       (__attribute__((address_space(3))) void*)(lds_dst + off0), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(lds_dst + off0), 16, 0, BC_DMA_CPOL);
   }
 }
 
