@@ -43,6 +43,26 @@ __global__ void scatter_load(const uint32_t* table, uint64_t range, uint32_t per
   if (acc == 0xFFFFFFFFu) sink[0] = acc;
 }
 
+// a reader that streams `bytes` once (plain or non-temporal loads), for the "atomics under streaming load" test
+template <int kNT>
+__global__ void stream_read(const uint4* __restrict__ src, uint64_t n16, uint32_t* sink) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  uint32_t acc = 0;
+  for (; i < n16; i += step) {
+    uint4 v;
+    if (kNT) {
+      typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+      const u4 t = __builtin_nontemporal_load(reinterpret_cast<const u4*>(src) + i);
+      v = make_uint4(t.x, t.y, t.z, t.w);
+    } else {
+      v = src[i];
+    }
+    acc += v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
+}
+
 int main() {
   const uint64_t max_entries = 4ull << 30;  // 16 GiB of u32
   uint32_t* table = nullptr;
@@ -86,6 +106,32 @@ int main() {
            r * 4.0 / (1 << 20), n / ms_a / 1e6, n / ms_l / 1e6, n / ms_p[0] / 1e6, n / ms_p[1] / 1e6, n / ms_p[2] / 1e6,
            n / ms_p[3] / 1e6);
     fflush(stdout);
+  }
+  // atomics confined to 256 MB while another stream reads 12 GB: does the Infinity Cache keep serving them?
+  {
+    hipStream_t sa, sb;
+    hipStreamCreateWithFlags(&sa, hipStreamNonBlocking);
+    hipStreamCreateWithFlags(&sb, hipStreamNonBlocking);
+    const uint64_t n16 = (12ull << 30) / 16;
+    const uint4* src = reinterpret_cast<const uint4*>(table + (1ull << 30));  // 4 GB into the table, clear of the atomics' range
+    for (int nt = 0; nt < 2; ++nt) {
+      for (uint64_t r : {1ull << 26, 4ull << 30}) {
+        hipDeviceSynchronize();
+        hipEventRecord(e0, sb);
+        for (int k = 0; k < 4; ++k) {
+          if (nt) hipLaunchKernelGGL(stream_read<1>, dim3(256 * 4), dim3(256), 0, sa, src, n16, sink);
+          else hipLaunchKernelGGL(stream_read<0>, dim3(256 * 4), dim3(256), 0, sa, src, n16, sink);
+        }
+        for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(scatter_add, dim3(blocks), dim3(threads), 0, sb, table, r, per, 999ull + k);
+        hipEventRecord(e1, sb);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        hipDeviceSynchronize();
+        printf("under a concurrent %s 12 GB x4 read: atomics over %6.0f MiB at %.2f G/s\n", nt ? "non-temporal" : "plain",
+               r * 4.0 / (1 << 20), 4 * n / ms / 1e6);
+      }
+    }
   }
   return 0;
 }
