@@ -20,6 +20,19 @@ __global__ void scatter_add(uint32_t* table, uint64_t range, uint32_t per, uint6
   }
 }
 
+// the same number of adds over the whole table, but region by region (64 regions): every line is touched at
+// most about once, so this isolates what address ORDER buys (DRAM pages, TLB) from what cache REUSE buys
+__global__ void scatter_add_by_region(uint32_t* table, uint64_t range, uint32_t per, uint64_t seed, uint32_t regions) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t total = (uint64_t)gridDim.x * blockDim.x * per;
+  const uint64_t rsize = range / regions;
+  for (uint32_t i = 0; i < per; ++i) {
+    const uint64_t op = (uint64_t)i * ((uint64_t)gridDim.x * blockDim.x) + t;  // consecutive threads, consecutive ops
+    const uint64_t region = op / (total / regions);
+    atomicAdd(&table[region * rsize + mix(seed + op) % rsize], 1u);
+  }
+}
+
 // the same with an explicit cache policy on the atomic instruction
 template <int kPolicy>
 __global__ void scatter_add_policy(uint32_t* table, uint64_t range, uint32_t per, uint64_t seed) {
@@ -106,6 +119,18 @@ int main() {
            r * 4.0 / (1 << 20), n / ms_a / 1e6, n / ms_l / 1e6, n / ms_p[0] / 1e6, n / ms_p[1] / 1e6, n / ms_p[2] / 1e6,
            n / ms_p[3] / 1e6);
     fflush(stdout);
+  }
+  for (uint32_t regions : {1u, 64u, 1024u, 16384u}) {
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+      hipEventRecord(e0);
+      hipLaunchKernelGGL(scatter_add_by_region, dim3(blocks), dim3(threads), 0, 0, table, max_entries, per, 4242ull + rep, regions);
+      hipEventRecord(e1);
+      hipEventSynchronize(e1);
+      hipEventElapsedTime(&ms, e0, e1);
+    }
+    printf("67 M adds over 16 GiB, ordered by region (%5u regions of %7.1f MiB): %6.2f G/s\n", regions,
+           max_entries * 4.0 / regions / (1 << 20), n / ms / 1e6);
   }
   // atomics confined to 256 MB while another stream reads 12 GB: does the Infinity Cache keep serving them?
   {
