@@ -712,8 +712,10 @@ struct ReadResult {
 //   void mark(int)                               -- profiling hook (no-op outside BC_PROFILE builds)
 //   const Quad* lhash(), bool tables()           -- the LDS exact-match area (plan.lhash_vec uint4s), and whether
 //                                                   it is loaded
-//   const uint32_t* stage_quality(uint32_t)      -- called once, by every lane, when the quality filter is
-//                                                   on: returns where the quality lines are
+//   const uint32_t* stage_quality(uint32_t n)    -- called once, by every lane, when the quality filter is
+//                                                   on: returns where the quality lines are; n = loads of its
+//                                                   own the lane code still has in flight
+//   void groups_done()                           -- called once after the last barcode group (experiments)
 // NW = 32-base words per read; NWW = words of candidate offsets / repair windows (len - L + 1 <= 32*NWW)
 template <class Ops, int NW, int NWW>
 BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32, uint32_t base, uint32_t len,
