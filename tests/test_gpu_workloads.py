@@ -139,3 +139,40 @@ def test_specialised_kernel_takes_over_in_the_background(monkeypatch, tmp_path):
     assert eng2.kernel_name().startswith("bc_jit_match_count")
     assert eng2.counters() == one
     eng2.close()
+
+
+@pytest.mark.parametrize("jit", ["0", "force"])
+def test_many_odd_sized_submits_equal_one_submit(monkeypatch, tmp_path, jit):
+    """the pipelined persistent kernel at every kind of batch edge: 3 M reads cut into ~300 submits of random sizes
+    (1 .. 40,000 reads, so full tiles, partial tiles, single reads, grids smaller than the chip) give exactly the
+    counters and the table of one submit"""
+    import torch
+    import ngs_barcode_count_amd as pkg
+    import workloads
+    monkeypatch.setenv("BC_JIT", jit)
+    monkeypatch.setenv("BC_JIT_CACHE", str(tmp_path / "cache"))
+    w = workloads.make("config3", n_sets=(4, 50, 60, 70))
+    n, R = 3_000_000, w.read_len
+    dseq = torch.empty(n * R, dtype=torch.uint8, device="cuda")
+    dqual = torch.empty(n * R, dtype=torch.uint8, device="cuda")
+    w.synth.generate_device(0, None, 0, n, dseq.data_ptr(), dqual.data_ptr())
+    torch.cuda.synchronize()
+    entries = w.plan.table_entries
+    t_one = torch.zeros(entries, dtype=torch.int32, device="cuda")
+    t_many = torch.zeros(entries, dtype=torch.int32, device="cuda")
+    one = pkg.Engine(w.plan, device=0, table_ptr=t_one.data_ptr())
+    one.submit_device(dseq.data_ptr(), dqual.data_ptr(), n, R, R)
+    many = pkg.Engine(w.plan, device=0, table_ptr=t_many.data_ptr())
+    rng = np.random.default_rng(77)
+    done = 0
+    while done < n:
+        k = int(min(n - done, rng.choice([1, 63, 64, 65, 255, 256, 257, int(rng.integers(1, 40001))])))
+        # batches must start 16-byte aligned: advance in multiples of 4 reads (R = 100 -> 400 bytes)
+        k = max(4, k - k % 4) if done + k < n else k
+        many.submit_device(dseq.data_ptr() + done * R, dqual.data_ptr() + done * R, k, R, R)
+        done += k
+    assert many.counters() == one.counters()
+    one.sync()
+    assert torch.equal(t_one, t_many)
+    one.close()
+    many.close()
