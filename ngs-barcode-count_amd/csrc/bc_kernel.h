@@ -108,6 +108,55 @@ __device__ __forceinline__ bool wave_scan_blocks(uint32_t nb, uint32_t blen, con
   return false;
 }
 
+// The coarse index (at most four long blocks, short buckets) in two memory round trips instead of two per block:
+// all bucket bounds first, then the first 64 entries of every bucket together; longer buckets finish in a loop.
+// Complete for nb - 1 mismatches: decided iff the best distance found is below nb.
+template <int kMaxBlocks>
+__device__ __forceinline__ bool wave_scan_blocks_wide(uint32_t nb, uint32_t blen, const BC_GLOBAL uint32_t* off_base,
+                                                      const BC_GLOBAL uint32_t* list_base, uint32_t n_idx, uint32_t q1,
+                                                      uint32_t q2, Nearest& s) {
+  const uint32_t bm = (1u << blen) - 1u;
+  const uint32_t nbk = 1u << (2 * blen);
+  const uint32_t lane = __lane_id();
+  const BC_GLOBAL uint4* entries = reinterpret_cast<const BC_GLOBAL uint4*>(list_base);
+  uint32_t beg[kMaxBlocks], end[kMaxBlocks];
+#pragma unroll
+  for (int b = 0; b < kMaxBlocks; ++b) {
+    beg[b] = end[b] = 0;
+    if ((uint32_t)b < nb) {
+      const uint32_t val = ((q1 >> (b * blen)) & bm) | (((q2 >> (b * blen)) & bm) << blen);
+      const BC_GLOBAL uint32_t* off = off_base + (size_t)b * (nbk + 1);
+      beg[b] = off[val];
+      end[b] = off[val + 1];
+    }
+  }
+  uint4 e[kMaxBlocks];
+#pragma unroll
+  for (int b = 0; b < kMaxBlocks; ++b) {
+    const uint32_t i = beg[b] + lane;
+    e[b] = make_uint4(0, 0, 0, 0);
+    if ((uint32_t)b < nb) e[b] = entries[(size_t)b * n_idx + (i < end[b] ? i : (beg[b] < end[b] ? beg[b] : 0u))];
+  }
+  auto score = [&](const uint4& x, uint32_t b, bool on) {
+    const uint32_t diff = (q1 ^ x.x) | (q2 ^ x.y);
+    bool earlier = false;  // equal to the capture on an earlier block: scored there
+    for (uint32_t p = 0; p < b; ++p) earlier = earlier || ((diff >> (p * blen)) & bm) == 0u;
+    if (on && !earlier) nearest_add(s, popc(diff), x.z, diff == 0u);
+  };
+#pragma unroll
+  for (int b = 0; b < kMaxBlocks; ++b) {
+    if ((uint32_t)b >= nb) continue;
+    score(e[b], (uint32_t)b, beg[b] + lane < end[b]);
+    for (uint32_t i = beg[b] + 64u + lane; i - lane < end[b]; i += 64u) {  // wave-uniform trip count
+      const bool on = i < end[b];
+      const uint4 x = entries[(size_t)b * n_idx + (on ? i : beg[b])];
+      score(x, (uint32_t)b, on);
+    }
+  }
+  const uint32_t kmin = wave_min_u32(s.key);
+  return kmin != 0xFFFFFFFFu && kmin <= nb;  // key = distance + 1
+}
+
 __device__ __forceinline__ void wave_seeded_min(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t& kmin_out,
                                                 bool& unique_out, uint32_t& idx_out) {
   const uint32_t lane = __lane_id();
@@ -116,7 +165,7 @@ __device__ __forceinline__ void wave_seeded_min(const DevGroup& G, uint32_t q1, 
   // the coarse index decides whenever some reference is within two mismatches (its three long blocks
   // make for short buckets); only otherwise is the full one, with its budget + 1 short blocks, walked
   bool decided = false;
-  if (G.seed2_nb) decided = wave_scan_blocks(G.seed2_nb, G.seed2_blen, G.seed2_off(), G.seed2_list(), G.n_idx, q1, q2, s);
+  if (G.seed2_nb) decided = wave_scan_blocks_wide<3>(G.seed2_nb, G.seed2_blen, G.seed2_off(), G.seed2_list(), G.n_idx, q1, q2, s);
   if (!decided) {
     nearest_init(s);  // whatever the coarse pass met is met again
     wave_scan_blocks(G.seed_nb, G.seed_blen, G.seed_off(), G.seed_list(), G.n_idx, q1, q2, s);
