@@ -373,13 +373,9 @@ struct DeviceOps {
 
   __device__ __forceinline__ bool any(bool c) const { return __any(c) != 0; }
   // the sequence bytes are dead once the planes are built: the next tile's sequence lines can land
-  bool late_fetch;  // experiment: request the next tile's sequence lines only after the gathers
   __device__ __forceinline__ void sequence_consumed() const {
     wave_lds_fence();
-    if (next_seq && !late_fetch) dma_tile(tile, next_seq, 64u * (bytes_per_read()), lane);
-  }
-  __device__ __forceinline__ void groups_done() const {
-    if (next_seq && late_fetch) dma_tile(tile, next_seq, 64u * (bytes_per_read()), lane);
+    if (next_seq) dma_tile(tile, next_seq, 64u * (bytes_per_read()), lane);
   }
   __device__ __forceinline__ uint32_t bytes_per_read() const { return stride_; }
   uint32_t stride_;
@@ -388,7 +384,7 @@ struct DeviceOps {
     if (qual_async) {
       // requested before the previous tile's counter atomic and the next tile's sequence lines: those
       // (and the caller's own loads) may stay in flight
-      wait_vm_keep(((next_seq && !late_fetch) ? chunks : 0u) + pending_add + younger);
+      wait_vm_keep((next_seq ? chunks : 0u) + pending_add + younger);
       wave_lds_fence();
       return reinterpret_cast<const uint32_t*>(qtile);
     }
@@ -467,7 +463,6 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
   const uint32_t full_bytes = 64u * stride;
   ops.chunks = (full_bytes + 1023u) / 1024u;
   ops.pending_add = 0;
-  ops.late_fetch = (pl.ablate & 0x400u) != 0u;
 
   // Persistent wavefronts: wave-tile t = 64 consecutive reads; this wave takes tiles
   // gid, gid + G, gid + 2G, ...  No workgroup barrier inside the loop; the outcome counters stay in

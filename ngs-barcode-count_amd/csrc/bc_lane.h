@@ -715,7 +715,6 @@ struct ReadResult {
 //   const uint32_t* stage_quality(uint32_t n)    -- called once, by every lane, when the quality filter is
 //                                                   on: returns where the quality lines are; n = loads of its
 //                                                   own the lane code still has in flight
-//   void groups_done()                           -- called once after the last barcode group (experiments)
 // NW = 32-base words per read; NWW = words of candidate offsets / repair windows (len - L + 1 <= 32*NWW)
 template <class Ops, int NW, int NWW>
 BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32, uint32_t base, uint32_t len,
@@ -1017,7 +1016,6 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
   if (!quality_done) quality_filter(0u);  // a scheme without barcode groups
   // a later group may still have failed the read: then that failure is the outcome, as in the reference
   if (raw_foreign && outcome == kMatched) unsupported = true;
-  ops.groups_done();
   // ---- random barcode: kept as captured, never corrected (parse.rs:510-516) ------------------
   if (pl.has_random) {
     uint32_t r1, r2, rn;

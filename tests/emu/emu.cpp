@@ -22,7 +22,6 @@ struct HostOps {
   const uint32_t* stage_quality(uint32_t) const { return qual32; }
   void sequence_consumed() const {}
   void mark(int) const {}
-  void groups_done() const {}
   bool any(bool c) const { return c; }
   uint32_t nearest(const bc::DevGroup& G, uint32_t q1, uint32_t q2, uint32_t qn, uint32_t qx, bool need) const {
     if (!need) return bc::kFail;
