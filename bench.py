@@ -97,13 +97,15 @@ def main():
     R = w.read_len
     with_qual = w.min_quality > 0
 
+    # the counter table first: it is the randomly accessed one, so it should get the most contiguous device memory
+    # (largest page fragments) the process can have
+    table = torch.zeros(w.plan.table_entries, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
     # --- resident inputs: this rank's contiguous shard of the seeded read stream -------------------
     dseq = torch.empty(n * R, dtype=torch.uint8, device=dev)
     dqual = torch.empty(n * R, dtype=torch.uint8, device=dev)
     first_read, _ = bcdist.shard(n * world, rank, world)
     w.synth.generate_device(local, None, first_read, n, dseq.data_ptr(), dqual.data_ptr())
-    torch.cuda.synchronize()
-    table = torch.zeros(w.plan.table_entries, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
     eng = pkg.Engine(w.plan, device=local, table_ptr=table.data_ptr())
     qptr = dqual.data_ptr() if with_qual else None

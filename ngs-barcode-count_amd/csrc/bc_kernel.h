@@ -252,6 +252,20 @@ __device__ __forceinline__ void stage_tile(uint8_t* __restrict__ dst, const uint
   for (uint32_t i = bytes + lane; i < region; i += 64) dst[i] = pad;
 }
 
+// the counter-table increment (no return value).  BC_ATOMIC_CPOL: cache-policy experiment (1 = nt, 2 = sc1)
+#ifndef BC_ATOMIC_CPOL
+#define BC_ATOMIC_CPOL 0
+#endif
+__device__ __forceinline__ void table_add(uint32_t* p) {
+#if BC_ATOMIC_CPOL == 1
+  asm volatile("global_atomic_add %0, %1, off nt" ::"v"(p), "v"(1u) : "memory");
+#elif BC_ATOMIC_CPOL == 2
+  asm volatile("global_atomic_add %0, %1, off sc1" ::"v"(p), "v"(1u) : "memory");
+#else
+  atomicAdd(p, 1u);
+#endif
+}
+
 // ---- device hash set of 64-bit keys (the AHashSet<String> per tuple of info.rs:663, flattened) ----
 constexpr unsigned long long kEmptyKey = ~0ull;
 
@@ -564,7 +578,7 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
           if (pl.sparse)
             atomicAdd(&vals[map_slot(slots, smask, r.dense_idx)], 1u);
           else
-            atomicAdd(&table[r.dense_idx], 1u);
+            table_add(&table[r.dense_idx]);
         }
         ops.pending_add = pl.sparse ? 0u : 1u;  // map_slot's compare-and-swap is waited for; the add is not
       }
