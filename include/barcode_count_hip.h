@@ -163,6 +163,11 @@ int bc_engine_key_count(bc_engine *e, uint64_t *n);
 int bc_engine_export_keys(bc_engine *e, void *d_keys, uint64_t capacity, uint64_t *n);
 int bc_engine_import_keys(bc_engine *e, const void *d_keys, uint64_t n, uint64_t *n_new);
 int bc_engine_clear_keys(bc_engine *e);
+/* Dense table + random barcode, several GPUs: after the key exchange every rank turns ITS (owned) keys into per-tuple
+ * distinct counts in its table with bc_engine_materialize_table; the tables are then summed onto the root
+ * (distributed.reduce_table), whose bc_engine_finish compacts the summed table as it stands.  (On one GPU
+ * bc_engine_finish materializes by itself.)  Any later submit / import / clear invalidates the materialized table. */
+int bc_engine_materialize_table(bc_engine *e);
 /* Plans that keep raw captures and have NO random barcode count in a (key -> count) map.  Across GPUs
  * the maps are merged by sending every (key, count) pair to the key's owner (or all of them to the
  * root), where bc_engine_import_counts adds them in.  export with NULL buffers only counts the pairs.
@@ -207,11 +212,12 @@ int bc_engine_sclk_mhz(bc_engine *e, double *mhz);
  * either way.  If no compiler is available the engine says so once on stderr.
  * Environment: BC_JIT=0 (never) | 1 (default) | force (compile synchronously at the first submit) |
  * cached (cache hits only).
- * bc_plan_precompile builds the kernel ahead of time without touching a GPU: nw = 32-base words per
- * read (4: reads up to 128 bases, 8: up to 256; longer reads stay on the generic kernel), nww = words of candidate
- * offsets ((read_len - scheme_len + 1 + 31) / 32), with_lens = per-read lengths will be passed,
- * cache_dir NULL = next to the library. */
-int bc_plan_precompile(const bc_plan *p, int nw, int nww, int with_lens, const char *cache_dir);
+ * A specialised kernel is also specific to the batch shape: the stride and, for fixed-length batches, the read
+ * length are compile-time constants of it (one kernel per shape; a FASTQ file has one or a few).
+ * bc_plan_precompile builds the kernel of one shape ahead of time without touching a GPU: stride / read_len as
+ * they will be passed to bc_engine_submit_* (reads of up to 256 bases; longer ones stay on the generic kernel),
+ * with_lens = per-read lengths will be passed (read_len is then ignored), cache_dir NULL = next to the library. */
+int bc_plan_precompile(const bc_plan *p, uint32_t stride, uint32_t read_len, int with_lens, const char *cache_dir);
 
 /* fix_error (parse.rs:553-593) on the device: nearest unique candidate under Hamming distance
  * with 'N' wildcards, common-prefix compare.  Returns the candidate index, -1 for None,

@@ -202,6 +202,10 @@ class Engine:
     def clear_keys(self):
         _check(self._lib, self._lib.bc_engine_clear_keys(self._e))
 
+    def materialize_table(self):
+        """random-barcode plans with a dense table: per-tuple distinct counts of the current key set -> the table"""
+        _check(self._lib, self._lib.bc_engine_materialize_table(self._e))
+
     def export_counts(self, d_keys, d_counts, capacity):
         """(key, count) pairs of a raw-key plan's map -> device buffers; None buffers: only their number"""
         n = C.c_uint64()
@@ -301,12 +305,13 @@ def make_set(seed, n, k, min_dist=1, lib=None):
     return [raw[i * (k + 1):i * (k + 1) + k].decode() for i in range(n)]
 
 
-def precompile(plan, nw=4, nww=2, lens=False, cache_dir=None):
-    """Builds the scheme-specialised match kernel of a plan ahead of time (no GPU needed) into the kernel
-    cache (default: jit_cache/ next to the library), so that engines of this plan find it ready.
-    nw = 32-base words per read (4: reads up to 128 bases), nww = words of candidate offsets."""
+def precompile(plan, stride=100, read_len=None, lens=False, cache_dir=None):
+    """Builds the scheme-specialised match kernel of a plan for one batch shape ahead of time (no GPU needed) into
+    the kernel cache (default: jit_cache/ next to the library), so that engines of this plan find it ready.
+    stride / read_len as they will be passed to submit_*; lens = per-read lengths will be passed."""
     lib = plan._lib
-    _check(lib, lib.bc_plan_precompile(plan._p, nw, nww, 1 if lens else 0, cache_dir.encode() if cache_dir else None))
+    _check(lib, lib.bc_plan_precompile(plan._p, stride, stride if read_len is None else read_len, 1 if lens else 0,
+                                       cache_dir.encode() if cache_dir else None))
 
 
 def fix_error(mismatch_seq, possible_seqs, mismatches, device=0, lib=None):

@@ -76,13 +76,14 @@ ENGINE_API = {
     "bc_table_sum_u8": (_int, [_vp, _u32, _u64, _vp, _int, _vp]),
     "bc_engine_kernel_name": (_cp, [_vp]),
     "bc_engine_sclk_mhz": (_int, [_vp, C.POINTER(C.c_double)]),
-    "bc_plan_precompile": (_int, [_vp, _int, _int, _int, _cp]),  # lives with the engine: it drives the device compiler
+    "bc_plan_precompile": (_int, [_vp, _u32, _u32, _int, _cp]),  # lives with the engine: it drives the device compiler
     "bc_engine_trace": (_int, [_vp, _vp, _vp]),
     "bc_engine_row_text": (_int, [_vp, _u64, _cp, _sz, _cp, _sz, C.POINTER(C.c_uint64)]),
     "bc_engine_key_count": (_int, [_vp, C.POINTER(C.c_uint64)]),
     "bc_engine_export_keys": (_int, [_vp, _vp, _u64, C.POINTER(C.c_uint64)]),
     "bc_engine_import_keys": (_int, [_vp, _vp, _u64, C.POINTER(C.c_uint64)]),
     "bc_engine_clear_keys": (_int, [_vp]),
+    "bc_engine_materialize_table": (_int, [_vp]),
     "bc_engine_export_counts": (_int, [_vp, _vp, _vp, _u64, C.POINTER(_u64)]),
     "bc_engine_import_counts": (_int, [_vp, _vp, _vp, _u64]),
     "bc_fix_error": (C.c_int64, [_cp, C.POINTER(_cp), _u64, C.c_uint16, _int]),

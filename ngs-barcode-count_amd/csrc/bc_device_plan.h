@@ -146,7 +146,8 @@ struct DevPlan {
   uint64_t rspace;      // 5^rnd_len: key = dense_idx * rspace + code
   uint32_t lhash_vec;   // uint4s of the LDS exact-match area (0: none); image of it at lhash_a
   uint64_t lhash_a;
-  uint32_t ablate;      // perf-debug only (env BC_ABLATE): bit mask of phases to skip; results are then wrong
+  uint32_t ablate;      // perf-debug only, honoured by -DBC_EXPERIMENT builds alone (`make experiment-lib`): bit mask of
+                        // phases to skip; results are then wrong.  The release library ignores the field (abl() == 0).
   // Per position class a program that walks the class's format positions in ascending order,
   // shifting the class vector right by the distance to the next position (0..31 per shift).
   //   prog_mode 0: prog[0 .. n3) are full triples s1 | s2 << 8 | s3 << 16 (three positions each, a
@@ -165,6 +166,11 @@ struct DevPlan {
   DevGroup groups[kMaxGroups];  // sample group first (if any), then counted barcodes in order, then random
 
   BC_HD uint64_t lhash_image() const { return BC_PLAN_ADDR(lhash_a, 0); }
+#ifdef BC_EXPERIMENT
+  BC_HD uint32_t abl() const { return ablate; }
+#else
+  BC_HD constexpr uint32_t abl() const { return 0u; }
+#endif
 };
 
 constexpr int kNCounters = 8;      // BC_NCOUNTERS

@@ -449,7 +449,7 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
   const uint32_t wave = tid >> 6;
   if (tid < kNCounters) s_cnt[tid] = 0;
 
-  const bool with_qual = pl.quality_on && !(pl.ablate & 0x8u);
+  const bool with_qual = pl.quality_on && !(pl.abl() & 0x8u);
   // flags bit 0: software-pipelined tile fetch (two LDS regions per wave with the quality filter on);
   // without it a wave has one region, filled on demand
   // flags bit 1: the plan's exact-match tables are copied into LDS and used
@@ -572,7 +572,7 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
     // fetches above are older: nothing in the next tile has to wait for the atomic to retire.
     ops.pending_add = 0;
     if (!pl.has_random) {
-      const bool add = active && outcome == kMatched && !pl.discard_counts && !(pl.ablate & 0x4u);
+      const bool add = active && outcome == kMatched && !pl.discard_counts && !(pl.abl() & 0x4u);
       if (__any(add)) {
         if (add) {
           if (pl.sparse)

@@ -415,7 +415,7 @@ BC_HD bool locate(const DevPlan& pl, Ops& ops, const Planes<NW>& P, const uint32
       if ((o >> 5) == (uint32_t)w) z[w] &= ~(1u << (o & 31u));
   }
 
-  if (!(pl.ablate & 0x1u) && ops.any(live && !found)) {
+  if (!(pl.abl() & 0x1u) && ops.any(live && !found)) {
     uint32_t cand[NWW];
     low_bits<NWW>(cand, len > L ? len - L : 0u);
 #pragma unroll
@@ -726,7 +726,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
 
   Planes<NW> P;
   uint32_t bad;
-  if (pl.ablate & 0x40u) {
+  if (pl.abl() & 0x40u) {
     bad = 0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) { P.p1[w] = base * 2654435761u + w; P.p2[w] = base * 40503u + w; P.pn[w] = 0; P.px[w] = 0; }
@@ -760,7 +760,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
     const bool live = active && !unsupported;
     // counter width is a compile-time constant; any width whose range covers max_const (or none
     // at all when no mismatch is allowed) gives the same verdicts
-    if (pl.ablate & 0x10u) {
+    if (pl.abl() & 0x10u) {
       found = true;
     } else if (pl.max_const == 0u) {
       found = locate<Ops, NW, NWW, 0>(pl, ops, P, inr, len, live, anyx, start, repaired);
@@ -787,7 +787,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
   // the quality fetch and need not land for it)
   auto quality_filter = [&](uint32_t in_flight) {
     quality_done = true;
-    if (pl.quality_on && !(pl.ablate & 0x8u)) {
+    if (pl.quality_on && !(pl.abl() & 0x8u)) {
       const uint32_t* qual32 = ops.stage_quality(in_flight);
       ops.mark(4);
       // after a repair the quality line is read from offset 0
@@ -817,7 +817,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
   uint64_t didx = 0;
   bool raw_foreign = false;
   const bool located = active && outcome == kMatched;  // anchored; the quality verdict is still to come
-  const uint32_t ng = (pl.ablate & 0x20u) ? 0u : pl.n_groups;
+  const uint32_t ng = (pl.abl() & 0x20u) ? 0u : pl.n_groups;
   // four groups at a time: first every capture is cut out and looked up (LDS, then the table gathers
   // of what LDS could not answer), then the verdicts are consumed in order
   for (uint32_t g0 = 0; g0 < ng; g0 += 4) {
@@ -862,7 +862,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
                 // no mismatch is allowed: then "not a reference" is already the verdict
                 r[u] = tl[u];
                 gather_m |= (r[u] == kFail && !(use_lds && G.lhash_complete && G.max_err == 0u)) ? (1u << u) : 0u;
-              } else if (qx[u] == 0u && !G.has_odd && (qn[u] & (qn[u] - 1u)) == 0u && !(pl.ablate & 0x100u)) {
+              } else if (qx[u] == 0u && !G.has_odd && (qn[u] & (qn[u] - 1u)) == 0u && !(pl.abl() & 0x100u)) {
                 if (use_lds && G.lhash_complete)
                   pend_n |= 1u << u;  // settled in LDS below, all groups in one pass
                 else
@@ -872,7 +872,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
               }
             } else if (G.mode == kSetHash) {
               need_m |= 1u << u;
-              if (!clean && qx[u] == 0u && (qn[u] & (qn[u] - 1u)) == 0u && G.tier_blen && !(pl.ablate & 0x800u)) {
+              if (!clean && qx[u] == 0u && (qn[u] & (qn[u] - 1u)) == 0u && G.tier_blen && !(pl.abl() & 0x800u)) {
                 bool settled = false;
                 const uint32_t t = tier_lookup_single_n(G, q1[u], q2[u], qn[u], settled);
                 if (settled) {
@@ -880,7 +880,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
                   need_m &= ~(1u << u);
                 }
               }
-              if (clean && G.tier_blen && !(pl.ablate & 0x800u)) {
+              if (clean && G.tier_blen && !(pl.abl() & 0x800u)) {
                 // the one-mismatch tier also finds the capture itself (distance 0): no separate exact lookup
                 bool settled = false;
                 const uint32_t t = tier_lookup(G, q1[u], q2[u], settled);
@@ -939,7 +939,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
       }
       pend_n &= pend_n - 1u;
     }
-    if (pl.ablate & 0x1000u) gather_m = 0;  // perf experiment: what the table round trip costs
+    if (pl.abl() & 0x1000u) gather_m = 0;  // perf experiment: what the table round trip costs
     // correction-table gathers of the captures LDS did not answer: all lanes load (the idle ones entry
     // 0, one shared cache line), so the four loads are in flight together
     uint32_t tv[4];
@@ -996,7 +996,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
         if (G.mode != kSetNone) {
           // a read that already failed an earlier group is not searched again (parse.rs:481, 500)
           bool nd_ = ((need_m >> u) & 1u) && outcome == kMatched;
-          if (pl.ablate & 0x2u) nd_ = false;
+          if (pl.abl() & 0x2u) nd_ = false;
           const uint32_t rr = ops.nearest(G, q1[u], q2[u], qn[u], qx[u], nd_);
           if (nd_) r[u] = rr;
           if (pre_ok && outcome == kMatched) {

@@ -1,11 +1,23 @@
 """Multi-GPU plumbing for the match/count path: reads shard trivially (no collective on the data
 path); at the end ONE sum-reduce of the dense counter tables and of the outcome counters
 (torch.distributed backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the CPU
-tests)."""
+tests).
+
+Stream contract: an Engine works on its own HIP stream, torch.distributed on torch's.  Every engine call used
+here returns only after its stream has drained (export_*, counters, materialize_table, sync), so what the engine
+produced is safe to hand to torch; in the other direction _torch_done() drains torch's stream before buffers a
+collective has written are handed to the engine."""
 import torch
 import torch.distributed as dist
 
 from ._lib import COUNTER_NAMES
+
+
+def _torch_done(t):
+    """collectives are enqueued on torch's stream without blocking the host: wait for them before the engine (its own
+    stream) reads what they wrote"""
+    if t.is_cuda:
+        torch.cuda.current_stream(t.device).synchronize()
 
 
 def shard(n_total, rank, world):
@@ -66,7 +78,8 @@ def reduce_table(table, dst=0, method=None):
       3. the summed slices are packed again and sent to dst point to point, one link each.
     A ring reduce of the raw table would push 16 GB (DEL workloads) through one link's bandwidth.
     Tables whose length is not a multiple of 4 x the world size, and method="reduce" /
-    BC_TABLE_REDUCE=reduce, use torch.distributed.reduce."""
+    BC_TABLE_REDUCE=reduce, use torch.distributed.reduce.  A failure of the packed exchange is raised, never
+    papered over: a rank that fell back on its own would leave its peers inside a different collective."""
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return table
     import os
@@ -76,13 +89,7 @@ def reduce_table(table, dst=0, method=None):
     if method == "reduce" or n % (4 * world) or n == 0:
         dist.reduce(table, dst=dst, op=dist.ReduceOp.SUM)
         return table
-    try:
-        return _reduce_table_packed(table, dst, world, rank, n)
-    except RuntimeError as err:  # a backend without one of the collectives used: same error on every rank
-        import sys
-        print("[barcode-count] packed table exchange unavailable (%s); using torch.distributed.reduce" % err, file=sys.stderr)
-        dist.reduce(table, dst=dst, op=dist.ReduceOp.SUM)
-        return table
+    return _reduce_table_packed(table, dst, world, rank, n)
 
 
 def _reduce_table_packed(table, dst, world, rank, n):
@@ -178,11 +185,12 @@ def exchange_keys(keys, counts=None, dst=None):
     return out, out_c
 
 
-def finish_random(engine, device, dst=0, gather=False):
+def finish_random(engine, device, dst=0, gather=False, table=None):
     """Global PCR-duplicate collapse: export this rank's keys, exchange them, keep
-    only the owned ones, fix the matched / duplicate counters, and leave per-tuple distinct counts
-    in the engine's table for reduce_table() + bc_engine_finish on the root.  Returns the global
-    counters on rank dst.
+    only the owned ones and fix the matched / duplicate counters.  Returns the global counters on rank dst.
+    Dense plans (table = the engine's counter table as a tensor): every rank then writes the per-tuple distinct
+    counts of the keys it owns into its table (bc_engine_materialize_table) and the tables are summed onto rank
+    dst, whose bc_engine_finish / Engine.rows() compacts that sum.
     gather=True (raw-key plans, whose results are a key map and not a table that could be summed):
     every key goes to rank dst, whose engine then holds the whole set."""
     local = engine.counters()
@@ -190,8 +198,15 @@ def finish_random(engine, device, dst=0, gather=False):
     keys = torch.empty(max(n, 1), dtype=torch.int64, device=device)
     engine.export_keys(keys.data_ptr(), n)
     recv = exchange_keys(keys[:n], dst=dst if gather else None)
+    _torch_done(recv)
     engine.clear_keys()
     owned = engine.import_keys(recv.data_ptr(), recv.numel()) if recv.numel() else 0
+    if not gather:
+        if table is None:
+            raise ValueError("finish_random: a dense plan needs table= (the tensor behind the engine's counter table)")
+        engine.materialize_table()  # returns when the engine's stream has drained
+        reduce_table(table, dst=dst)
+        _torch_done(table)
     fixed = dict(local)
     # every locally matched read is either the one owner-side survivor of its key or a duplicate
     fixed["duplicates"] = local["duplicates"] + local["matched"] - owned
@@ -212,6 +227,7 @@ def finish_sparse(engine, device, dst=0):
     cnts = torch.empty(max(n, 1), dtype=torch.int32, device=device)
     engine.export_counts(keys.data_ptr(), cnts.data_ptr(), n)
     rk, rc = exchange_keys(keys[:n], cnts[:n], dst=dst)
+    _torch_done(rk)
     engine.clear_keys()
     if rk.numel():
         engine.import_counts(rk.data_ptr(), rc.data_ptr(), rk.numel())

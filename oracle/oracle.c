@@ -30,6 +30,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 
 /* ------------------------------------------------------------------ */
 /* small string-keyed hash map (stands in for ahash HashMap / AHashSet) */
@@ -194,6 +195,11 @@ struct orc_ctx {
   /* scratch */
   char *seqbuf;
   size_t seqcap;
+
+  /* orc_run_reference_threads: this context is one worker's clone of the static inputs (src/main.rs:95-102); its
+   * add_count goes to the job's one shared Results under the job's one mutex (Arc<Mutex<Results>>, src/parse.rs:60) */
+  struct orc_ctx *shared_results;
+  void *results_mutex; /* pthread_mutex_t* */
 };
 
 static char *xstrndup(const char *s, size_t n) {
@@ -992,7 +998,14 @@ int orc_process_read(orc_ctx *c, const char *seq_in, size_t seqlen, const char *
     random_len = c->groups[c->random_group].len;
   }
   /* parse.rs:58-69 */
-  int added = add_count(c, sample_barcode, sample_len, random, random_len, random != NULL, tuple.p, tuple.n);
+  int added;
+  if (c->shared_results) { /* self.shared_mut.results.lock().unwrap().add_count(..), parse.rs:60-64 */
+    pthread_mutex_lock((pthread_mutex_t *)c->results_mutex);
+    added = add_count(c->shared_results, sample_barcode, sample_len, random, random_len, random != NULL, tuple.p, tuple.n);
+    pthread_mutex_unlock((pthread_mutex_t *)c->results_mutex);
+  } else {
+    added = add_count(c, sample_barcode, sample_len, random, random_len, random != NULL, tuple.p, tuple.n);
+  }
   free(tuple.p);
   if (added) {
     c->counters[ORC_MATCHED]++;
@@ -1010,6 +1023,141 @@ void orc_process_batch(orc_ctx *c, const uint8_t *seq, const uint8_t *qual, cons
     const char *q = qual ? (const char *)qual + (size_t)i * stride : "";
     orc_process_read(c, s, l, q, qual ? l : 0);
   }
+}
+
+/* ------------------------------------------------------------------ */
+/* The reference's own thread structure, for the CPU baseline: one reader  */
+/* thread posting packed 4-line records to a mutex-guarded deque with the  */
+/* 10,000-record back-pressure spin (src/input.rs:115-148), threads-1     */
+/* workers popping from it and busy-spinning while it is empty            */
+/* (src/parse.rs:53-86), one mutex-guarded Results (src/parse.rs:60-64).  */
+/* ------------------------------------------------------------------ */
+typedef struct qnode {
+  struct qnode *prev, *next;
+  size_t len;
+  char rec[];
+} qnode;
+
+typedef struct {
+  pthread_mutex_t qmu; /* Arc<Mutex<VecDeque<String>>> */
+  qnode *front, *back;
+  size_t qlen;
+  volatile int finished; /* Arc<AtomicBool> */
+  pthread_mutex_t rmu; /* Arc<Mutex<Results>> */
+  const uint8_t *seq, *qual;
+  uint32_t stride, read_len;
+  uint64_t n;
+} refjob;
+
+static void *ref_reader(void *arg) { /* read_fastq, src/input.rs:24-89 */
+  refjob *j = (refjob *)arg;
+  for (uint64_t i = 0; i < j->n; i++) {
+    /* the record as the reference queues it: "desc\nseq\n+\nqual" (src/input.rs:124-147) */
+    size_t rl = j->read_len, len = 2 + rl + 3 + rl;
+    qnode *nd = (qnode *)malloc(sizeof(qnode) + len + 1);
+    char *p = nd->rec;
+    *p++ = '@';
+    *p++ = '\n';
+    memcpy(p, j->seq + (size_t)i * j->stride, rl);
+    p += rl;
+    *p++ = '\n';
+    *p++ = '+';
+    *p++ = '\n';
+    if (j->qual) memcpy(p, j->qual + (size_t)i * j->stride, rl); else memset(p, 'I', rl);
+    p[rl] = 0;
+    nd->len = len;
+    for (;;) { /* back-pressure: spin while 10,000 records are queued (src/input.rs:117-122) */
+      pthread_mutex_lock(&j->qmu);
+      if (j->qlen < 10000) break;
+      pthread_mutex_unlock(&j->qmu);
+    }
+    nd->prev = NULL; /* push_front (src/input.rs:147) */
+    nd->next = j->front;
+    if (j->front) j->front->prev = nd; else j->back = nd;
+    j->front = nd;
+    j->qlen++;
+    pthread_mutex_unlock(&j->qmu);
+  }
+  j->finished = 1; /* src/main.rs:88 */
+  return NULL;
+}
+
+typedef struct {
+  refjob *job;
+  orc_ctx *ctx;
+} refworker;
+
+static void *ref_worker(void *arg) { /* SequenceParser::parse, src/parse.rs:53-76 */
+  refworker *w = (refworker *)arg;
+  refjob *j = w->job;
+  for (;;) {
+    pthread_mutex_lock(&j->qmu); /* get_seqeunce: lock, pop_back (src/parse.rs:78-86) */
+    qnode *nd = j->back;
+    if (nd) {
+      j->back = nd->prev;
+      if (j->back) j->back->next = NULL; else j->front = NULL;
+      j->qlen--;
+    }
+    pthread_mutex_unlock(&j->qmu);
+    if (!nd) {
+      if (j->finished) { /* queue empty and the reader is done (src/parse.rs:71-73); re-check under the lock */
+        pthread_mutex_lock(&j->qmu);
+        int empty = j->back == NULL;
+        pthread_mutex_unlock(&j->qmu);
+        if (empty) break;
+      }
+      continue; /* busy spin: the reference has no condvar */
+    }
+    /* RawSequenceRead::unpack: split on '\n' into the four lines (src/parse.rs:260-267) */
+    const char *l1 = memchr(nd->rec, '\n', nd->len);
+    const char *s = l1 + 1;
+    const char *l2 = memchr(s, '\n', nd->len - (size_t)(s - nd->rec));
+    const char *l3 = memchr(l2 + 1, '\n', nd->len - (size_t)(l2 + 1 - nd->rec));
+    const char *q = l3 + 1;
+    orc_process_read(w->ctx, s, (size_t)(l2 - s), q, nd->len - (size_t)(q - nd->rec));
+    free(nd);
+  }
+  return NULL;
+}
+
+/* workers[0 .. n_workers): identically configured contexts (the per-worker clones); shared: one more, whose Results
+ * receives every add_count.  Counters end up per worker (sum them).  Returns 0, or -1 when a thread cannot start. */
+int orc_run_reference_threads(orc_ctx **workers, uint32_t n_workers, orc_ctx *shared, const uint8_t *seq,
+                              const uint8_t *qual, uint32_t stride, uint32_t read_len, uint64_t n) {
+  refjob j;
+  memset(&j, 0, sizeof j);
+  pthread_mutex_init(&j.qmu, NULL);
+  pthread_mutex_init(&j.rmu, NULL);
+  j.seq = seq;
+  j.qual = qual;
+  j.stride = stride;
+  j.read_len = read_len;
+  j.n = n;
+  if (!shared->results_init) orc_begin(shared);
+  refworker *ws = (refworker *)calloc(n_workers, sizeof(refworker));
+  pthread_t *th = (pthread_t *)calloc(n_workers + 1, sizeof(pthread_t));
+  int rc = 0;
+  uint32_t started = 0;
+  for (uint32_t k = 0; k < n_workers; k++) {
+    workers[k]->shared_results = shared;
+    workers[k]->results_mutex = &j.rmu;
+    ws[k].job = &j;
+    ws[k].ctx = workers[k];
+    if (pthread_create(&th[k], NULL, ref_worker, &ws[k]) != 0) { rc = -1; break; }
+    started++;
+  }
+  if (rc == 0) ref_reader(&j); /* the calling thread is the reader */
+  j.finished = 1;
+  for (uint32_t k = 0; k < started; k++) pthread_join(th[k], NULL);
+  for (uint32_t k = 0; k < n_workers; k++) {
+    workers[k]->shared_results = NULL;
+    workers[k]->results_mutex = NULL;
+  }
+  free(ws);
+  free(th);
+  pthread_mutex_destroy(&j.qmu);
+  pthread_mutex_destroy(&j.rmu);
+  return rc;
 }
 
 void orc_counters(const orc_ctx *c, uint64_t out[ORC_NCOUNTERS]) { memcpy(out, c->counters, sizeof c->counters); }

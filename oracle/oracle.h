@@ -94,6 +94,14 @@ int orc_process_read(orc_ctx *c, const char *seq, size_t seqlen, const char *qua
 void orc_process_batch(orc_ctx *c, const uint8_t *seq, const uint8_t *qual, const uint16_t *lens, uint32_t stride,
                        uint32_t read_len, uint64_t n);
 
+/* The same reads through the reference's own thread structure (bench.py's cpu_baseline): the calling thread is the
+ * reader posting packed 4-line records to a mutex-guarded deque (10,000-record back-pressure spin,
+ * src/input.rs:115-148), n_workers threads pop and match (busy spin while empty, src/parse.rs:53-86) on their own
+ * clone of the static inputs (src/main.rs:95-102) and add into ONE Results -- `shared`'s -- under one mutex
+ * (src/parse.rs:60-64).  Outcome counters stay per worker context: sum them. */
+int orc_run_reference_threads(orc_ctx **workers, uint32_t n_workers, orc_ctx *shared, const uint8_t *seq,
+                              const uint8_t *qual, uint32_t stride, uint32_t read_len, uint64_t n);
+
 void orc_counters(const orc_ctx *c, uint64_t out[ORC_NCOUNTERS]);
 /* reads whose handling is undefined in the reference (len < format length:
  * usize underflow at src/parse.rs:291); counted as constant-region errors */

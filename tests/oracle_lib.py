@@ -54,6 +54,8 @@ def lib():
         L.orc_process_read.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
         L.orc_process_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                         C.c_uint64]
+        L.orc_run_reference_threads.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_uint32, C.c_uint32, C.c_uint64]
         L.orc_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.orc_undefined_reads.restype = C.c_uint64
         L.orc_undefined_reads.argtypes = [C.c_void_p]
@@ -73,6 +75,23 @@ def lib():
         L.orc_counted_id.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p]
         _lib = L
     return _lib
+
+
+def run_reference_threads(workers, shared, seq, qual, stride, read_len):
+    """the reads through the reference's thread structure: 1 reader (this thread) + len(workers) worker threads popping
+    a mutex-guarded deque, one mutex-guarded Results (`shared`'s).  Returns the summed outcome counters."""
+    L = lib()
+    n = seq.size // stride
+    arr = (C.c_void_p * len(workers))(*[w._c for w in workers])
+    rc = L.orc_run_reference_threads(arr, len(workers), shared._c, seq.ctypes.data,
+                                     qual.ctypes.data if qual is not None else None, stride, read_len, n)
+    if rc != 0:
+        raise RuntimeError("orc_run_reference_threads: could not start the worker threads")
+    total = dict.fromkeys(NAMES, 0)
+    for w in workers:
+        for k, v in w.counters.items():
+            total[k] += v
+    return total
 
 
 def fix_error(query, candidates, max_mismatches):
