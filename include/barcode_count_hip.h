@@ -122,6 +122,14 @@ void bc_engine_destroy(bc_engine *e);
  * hipMemcpyAsync on a side stream and returns when the host buffers may be reused. */
 int bc_engine_submit_device(bc_engine *e, const void *d_seq, const void *d_qual, const void *d_lens, uint32_t stride,
                             uint32_t read_len, uint64_t n_reads);
+/* The same for records whose quality line is not as long as their sequence line (trimmed or damaged files): the
+ * reference zips the scores with the regions (parse.rs:340-345), so what counts is the quality line's own length.
+ * d_lens / d_qlens: u16 per read, both required; the first min(qlen, stride) quality bytes are stored at the stride. */
+int bc_engine_submit_device_q(bc_engine *e, const void *d_seq, const void *d_qual, const void *d_lens, const void *d_qlens,
+                              uint32_t stride, uint64_t n_reads);
+/* the engine's stream (a hipStream_t) and device, for callers that produce batches on the device themselves */
+void *bc_engine_hip_stream(bc_engine *e);
+int bc_engine_device(const bc_engine *e);
 int bc_engine_submit_host(bc_engine *e, const void *seq, const void *qual, const uint16_t *lens, uint32_t stride,
                           uint32_t read_len, uint64_t n_reads);
 int bc_engine_sync(bc_engine *e);
@@ -201,6 +209,11 @@ const char *bc_engine_kernel_name(bc_engine *e);
  * 100 MHz reference counter.  Call it straight after the work of interest: the clock sags under power
  * and thermal limits, and the match kernel's time follows it. */
 int bc_engine_sclk_mhz(bc_engine *e, double *mhz);
+
+/* Box diagnostic for benchmarks: issues ~n_atomics no-return atomic adds of ZERO (the table's contents stay what they
+ * are) at random entries of a u32 table and reports the sustained rate -- what the memory system of THIS device gives
+ * the match kernel's counting alone (it differs between boxes by tens of percent). */
+int bc_probe_atomic_rate(int device_id, void *d_table_u32, uint64_t entries, uint64_t n_atomics, double *atomics_per_s);
 
 /* Scheme-specialised kernels.  Next to the generic kernel (any plan, plan read from memory) an engine
  * can run one compiled for its plan's scheme (offsets, shift programs, thresholds and set sizes as

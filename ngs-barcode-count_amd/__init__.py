@@ -144,6 +144,10 @@ class Engine:
     def submit_device(self, d_seq, d_qual, n_reads, stride, read_len, d_lens=None):
         _check(self._lib, self._lib.bc_engine_submit_device(self._e, d_seq, d_qual, d_lens, stride, read_len, n_reads))
 
+    def submit_device_q(self, d_seq, d_qual, n_reads, stride, d_lens, d_qlens):
+        """records whose quality line differs in length from the sequence line: both length arrays (u16, device)"""
+        _check(self._lib, self._lib.bc_engine_submit_device_q(self._e, d_seq, d_qual, d_lens, d_qlens, stride, n_reads))
+
     def submit_host(self, seq, qual, stride, read_len, lens=None):
         seq = np.ascontiguousarray(seq, dtype=np.uint8)
         n = seq.size // stride
@@ -232,6 +236,12 @@ class Engine:
         _check(self._lib, self._lib.bc_engine_kernel_ms(self._e, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def finish(self):
+        """bc_engine_finish: compacts the results into sparse rows; returns their number"""
+        n = C.c_uint64()
+        _check(self._lib, self._lib.bc_engine_finish(self._e, C.byref(n)))
+        return n.value
+
     def rows(self):
         """-> (sample_idx[n], barcode_idx[n, barcode_num], count[n]) of the non-zero table entries"""
         n = C.c_uint64()
@@ -303,6 +313,14 @@ def make_set(seed, n, k, min_dist=1, lib=None):
     _check(lib, rc)
     raw = buf.raw
     return [raw[i * (k + 1):i * (k + 1) + k].decode() for i in range(n)]
+
+
+def probe_atomic_rate(device, table_ptr, entries, n_atomics, lib=None):
+    """random no-return atomic adds of 0 per second over a u32 table on this device (box diagnostic)"""
+    lib = lib or _lib.load()
+    v = C.c_double()
+    _check(lib, lib.bc_probe_atomic_rate(int(device), table_ptr, entries, n_atomics, C.byref(v)))
+    return v.value
 
 
 def precompile(plan, stride=100, read_len=None, lens=False, cache_dir=None):

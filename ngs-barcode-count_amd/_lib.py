@@ -61,6 +61,9 @@ ENGINE_API = {
     "bc_engine_create": (_vp, [_vp, _int, _vp, _vp]),
     "bc_engine_destroy": (None, [_vp]),
     "bc_engine_submit_device": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u64]),
+    "bc_engine_submit_device_q": (_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u64]),
+    "bc_engine_hip_stream": (_vp, [_vp]),
+    "bc_engine_device": (_int, [_vp]),
     "bc_engine_submit_host": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u64]),
     "bc_engine_sync": (_int, [_vp]),
     "bc_engine_reset": (_int, [_vp]),
@@ -83,6 +86,7 @@ ENGINE_API = {
     "bc_engine_export_keys": (_int, [_vp, _vp, _u64, C.POINTER(C.c_uint64)]),
     "bc_engine_import_keys": (_int, [_vp, _vp, _u64, C.POINTER(C.c_uint64)]),
     "bc_engine_clear_keys": (_int, [_vp]),
+    "bc_probe_atomic_rate": (_int, [_int, _vp, _u64, _u64, C.POINTER(C.c_double)]),
     "bc_engine_materialize_table": (_int, [_vp]),
     "bc_engine_export_counts": (_int, [_vp, _vp, _vp, _u64, C.POINTER(_u64)]),
     "bc_engine_import_counts": (_int, [_vp, _vp, _vp, _u64]),

@@ -433,9 +433,11 @@ struct DeviceOps {
 // ------------------------------------------------------------------------------------------------
 // kLens: per-read lengths are given.  A separate instantiation because the length load would
 // otherwise put a full vector-memory wait into every iteration, fetches in flight or not.
-template <int NW, int NWW, bool kLens>
+// kAligned: the stride is a multiple of 4 (known only to a kernel specialised for its batch shape)
+template <int NW, int NWW, bool kLens, bool kAligned = false>
 __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_t* __restrict__ seq,
                                                  const uint8_t* __restrict__ qual, const uint16_t* __restrict__ lens,
+                                                 const uint16_t* __restrict__ qlens,
                                                  uint32_t stride, uint32_t read_len, uint32_t nd, uint64_t n_reads,
                                                  uint32_t region, uint32_t* __restrict__ table,
                                                  unsigned long long* __restrict__ slots, uint32_t* __restrict__ vals,
@@ -535,9 +537,12 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
     const bool active = lane < n_w;
     uint32_t len = 0;
     if (active) len = kLens ? (uint32_t)lens[wfirst + lane] : read_len;
+    // the quality line's own length, when it differs from the sequence line's (zip truncation, parse.rs:340-345)
+    uint32_t qlen = len;
+    if (kLens && qlens && active) qlen = (uint32_t)qlens[wfirst + lane];
     const uint32_t base = (active ? lane : 0u) * stride;
     const ReadResult r =
-        process_read<DeviceOps, NW, NWW>(pl, ops, reinterpret_cast<const uint32_t*>(ops.tile), base, len, nd, active);
+        process_read<DeviceOps, NW, NWW, kAligned>(pl, ops, reinterpret_cast<const uint32_t*>(ops.tile), base, len, qlen, nd, active);
 
     ops.mark(8);
     uint32_t outcome = r.outcome;

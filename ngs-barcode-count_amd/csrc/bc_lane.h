@@ -13,6 +13,13 @@
 #include "bc_device_plan.h"
 #include "bc_intrin.h"
 
+// candidate windows a specialised kernel has to get right: its batch's read length is a compile-time constant
+#if defined(BC_JIT_TU) && JIT_READ_LEN
+#define BC_STATIC_CAND(L, NWW) ((uint32_t)JIT_READ_LEN >= (L) ? (uint32_t)JIT_READ_LEN - (L) + 1u : 0u)
+#else
+#define BC_STATIC_CAND(L, NWW) (32u * (uint32_t)(NWW))
+#endif
+
 namespace bc {
 
 template <int NW>
@@ -33,10 +40,16 @@ BC_HD uint64_t hash64(uint64_t x) {
 }
 
 // ---- ASCII -> bit planes -------------------------------------------------------------------
-// Fast conversion: 4 bases per dword, three v_dot4_u32_u8 gathers per dword.  `bad` ends up
-// non-zero when any converted byte is not one of A,C,G,T,N; the planes are then only valid
-// after pack_exact() has rebuilt pn/px.
-template <int NW>
+// Fast conversion, eight bases (two dwords d0, d1) at a time.  The plane bits of a base are ASCII bits 1, 2 and 3
+// (A=000 C=001 T=010 G=011 N=111).  M = (d0 >> 1 on bits 0-2 of every byte) | (d1 << 3 on bits 4-6): one word that
+// holds the three bits of all eight bases, so that ONE v_dot4_u32_u8 per plane (weights 1, 2, 4, 8 on the masked
+// nibbles) gathers eight plane bits in base order.  Planes 2 and N are taken from M at their own bit (mask
+// 0x22.., 0x44..), which scales the gathered byte by 2 / 4: the shift that puts the byte into its plane word
+// absorbs that.  `bad` ends up non-zero when any converted byte is not one of A,C,G,T,N (the byte rebuilt from its
+// three bits by a v_perm_b32 table differs from the byte itself); the planes are then only valid after
+// pack_exact() has rebuilt pn/px.
+// kAligned: every read starts on a dword of the tile (the stride is a multiple of 4): no byte realignment
+template <int NW, bool kAligned>
 BC_HD void pack_read(const uint32_t* t32, uint32_t base, uint32_t nd, Planes<NW>& P, uint32_t& bad) {
   const uint32_t a = base & 3u;
   const uint32_t* src = t32 + (base >> 2);
@@ -50,23 +63,30 @@ BC_HD void pack_read(const uint32_t* t32, uint32_t base, uint32_t nd, Planes<NW>
     uint32_t o1 = 0, o2 = 0, on = 0;
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
-      uint32_t a1 = 0, a2 = 0, an = 0;
       if ((uint32_t)(w * 8 + h * 2) < nd) {  // wave-uniform, per 8 bases
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int idx = w * 8 + h * 2 + j;
-          const uint32_t d = alignbyte(raw[idx + 1], raw[idx], a);
-          const uint32_t wt = j ? 0x80402010u : 0x08040201u;
-          a1 = udot4(d & 0x02020202u, wt, a1);
-          a2 = udot4(d & 0x04040404u, wt, a2);
-          an = udot4(d & 0x08080808u, wt, an);
-          const uint32_t ex = perm(0x4EFFFFFFu, 0x47544341u, (d >> 1) & 0x07070707u);
-          bad = sad_u8(d, ex, bad);
+        const int idx = w * 8 + h * 2;
+        const uint32_t d0 = kAligned ? raw[idx] : alignbyte(raw[idx + 1], raw[idx], a);
+        // the pair's second dword may lie past the read (nd odd): its bits land past the read too
+        const uint32_t d1 = kAligned ? raw[idx + 1] : alignbyte(raw[idx + 2 <= NW * 8 ? idx + 2 : idx + 1], raw[idx + 1], a);
+        const uint32_t m = bitop3<0xE4>(d0 >> 1, d1 << 3, 0x07070707u);  // (a & c) | (b & ~c)
+        const uint32_t g1 = udot4(m & 0x11111111u, 0x08040201u, 0u);      // plane-1 bits of the 8 bases
+        const uint32_t g2 = udot4(m & 0x22222222u, 0x08040201u, 0u);      // plane-2 bits, times 2
+        const uint32_t gn = udot4(m & 0x44444444u, 0x08040201u, 0u);      // N bits, times 4
+        if (h == 0) {
+          o1 = g1;
+          o2 = g2 >> 1;
+          on = gn >> 2;
+        } else {
+          o1 |= g1 << (8 * h);
+          o2 |= g2 << (8 * h - 1);
+          on |= gn << (8 * h - 2);
         }
+        // validity: ACGTN rebuilt from the three bits must give the byte back
+        const uint32_t e0 = perm(0x4EFFFFFFu, 0x47544341u, m & 0x07070707u);
+        const uint32_t e1 = perm(0x4EFFFFFFu, 0x47544341u, (m >> 4) & 0x07070707u);
+        bad = bitop3<0xF6>(bad, d0, e0);  // bad | (d0 ^ e0)
+        if ((uint32_t)(idx + 1) < nd) bad = bitop3<0xF6>(bad, d1, e1);
       }
-      o1 |= (a1 >> 1) << (8 * h);
-      o2 |= (a2 >> 2) << (8 * h);
-      on |= (an >> 3) << (8 * h);
     }
     P.p1[w] = o1;
     P.p2[w] = o2;
@@ -256,8 +276,8 @@ BC_HD void add_bits(Counters<NWW, NB>& C, int w, uint32_t s, uint32_t c) {
 // Mismatch count of every window against the constant bases of the format (the inner loops of
 // fix_error, parse.rs:562-575, for all windows of fix_constant_region, parse.rs:291-304, at once).
 // A read base equal to the format base, or 'N', is no mismatch (parse.rs:569).
-template <int NW, int NWW, int NB>
-BC_HD void count_mismatches(const DevPlan& pl, const Planes<NW>& P, bool anyx, Counters<NWW, NB>& C) {
+template <int NW, int NWW, int NB, bool kAnyX>
+BC_HD void count_mismatches(const DevPlan& pl, const Planes<NW>& P, Counters<NWW, NB>& C) {
 #pragma unroll
   for (int w = 0; w < NWW; ++w) {
     C.ovf[w] = 0;
@@ -277,7 +297,7 @@ BC_HD void count_mismatches(const DevPlan& pl, const Planes<NW>& P, bool anyx, C
            : c == 1 ? bitop3<0xBA>(P.p1[w], P.p2[w], P.pn[w])
            : c == 2 ? bitop3<0xAE>(P.p1[w], P.p2[w], P.pn[w])
                     : bitop3<0xEA>(P.p1[w], P.p2[w], P.pn[w]);
-      if (anyx) v[w] &= ~P.px[w];  // a foreign byte never matches
+      if (kAnyX) v[w] &= ~P.px[w];  // a foreign byte never matches
     }
     const uint32_t* pp = pl.prog[c];
     const uint32_t n = pl.n3[c];
@@ -323,6 +343,189 @@ BC_HD void count_mismatches(const DevPlan& pl, const Planes<NW>& P, bool anyx, C
   }
 }
 
+// ---- the same counts for a kernel specialised to its scheme (every format position a compile-time constant) --------
+// calls f(p) for every format position p of class c, in ascending order (the decoding of DevPlan::prog)
+template <class F>
+BC_HD void for_each_position(const DevPlan& pl, int c, F&& f) {
+  const uint32_t* pp = pl.prog[c];
+  const uint32_t n = pl.n3[c];
+  uint32_t pos = 0;
+  if (pl.prog_mode[c] == 0u) {
+#pragma unroll
+    for (uint32_t i = 0; i < n; ++i) {
+      const uint32_t e = pp[i];
+      pos += e & 31u;
+      f(pos);
+      pos += (e >> 8) & 31u;
+      f(pos);
+      pos += (e >> 16) & 31u;
+      f(pos);
+    }
+    const uint32_t e = pp[n], k = e >> 24;
+    if (k >= 1u) {
+      pos += e & 31u;
+      f(pos);
+    }
+    if (k == 2u) {
+      pos += (e >> 8) & 31u;
+      f(pos);
+    }
+  } else {
+#pragma unroll
+    for (uint32_t i = 0; i < n; ++i) {
+      const uint32_t e = pp[i];
+      pos += e & 31u;
+      if (e >> 24) f(pos);
+    }
+  }
+}
+
+// Carry-save accumulation of one-bit vectors: level l holds at most two pending vectors of weight 2^l; a third
+// one turns the three into a sum (stays) and a carry (moves up) with two v_bitop3_b32 per word.  In a fully unrolled
+// specialised kernel the fill counts are compile-time constants, so this is straight-line code: n vectors cost about
+// n - log2(n) full adders instead of the n/3 * (2 + NB + 2) operations of the ripple counters above.
+template <int NWW, int kLevels>
+struct CsaCounter {
+  uint32_t pend[kLevels][2][NWW];
+  int fill[kLevels];
+  uint32_t over[NWW];  // carries out of the top level
+  BC_HD void init() {
+#pragma unroll
+    for (int l = 0; l < kLevels; ++l) fill[l] = 0;
+#pragma unroll
+    for (int w = 0; w < NWW; ++w) over[w] = 0;
+  }
+  BC_HD void add(const uint32_t (&x)[NWW]) {
+    // (no array is indexed by a fill count and nothing returns early: every branch below folds away once the
+    // caller's loops are unrolled, and until then there is nothing that would need scratch memory)
+    uint32_t carry[NWW];
+#pragma unroll
+    for (int w = 0; w < NWW; ++w) carry[w] = x[w];
+    bool live = true;
+#pragma unroll
+    for (int l = 0; l < kLevels; ++l) {
+      if (!live) continue;
+      if (fill[l] == 0) {
+#pragma unroll
+        for (int w = 0; w < NWW; ++w) pend[l][0][w] = carry[w];
+        fill[l] = 1;
+        live = false;
+      } else if (fill[l] == 1) {
+#pragma unroll
+        for (int w = 0; w < NWW; ++w) pend[l][1][w] = carry[w];
+        fill[l] = 2;
+        live = false;
+      } else {
+#pragma unroll
+        for (int w = 0; w < NWW; ++w) {
+          const uint32_t a = pend[l][0][w], b = pend[l][1][w], c = carry[w];
+          pend[l][0][w] = bitop3<kTT_Xor3>(a, b, c);
+          carry[w] = bitop3<kTT_Maj>(a, b, c);
+        }
+        fill[l] = 1;
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int w = 0; w < NWW; ++w) over[w] |= carry[w];
+    }
+  }
+  // final bits: bit[l][w] = bit l of the count of every window; overflow past the top level in over[]
+  BC_HD void finish(uint32_t (&bit)[kLevels][NWW]) {
+    uint32_t carry[NWW];
+#pragma unroll
+    for (int w = 0; w < NWW; ++w) carry[w] = 0;
+    bool have_carry = false;
+#pragma unroll
+    for (int l = 0; l < kLevels; ++l) {
+      // the level's pending vectors plus the carry from below: up to three one-bit vectors
+      const int n = fill[l] + (have_carry ? 1 : 0);
+#pragma unroll
+      for (int w = 0; w < NWW; ++w) {
+        const uint32_t a = fill[l] >= 1 ? pend[l][0][w] : 0u;
+        const uint32_t b = fill[l] >= 2 ? pend[l][1][w] : 0u;
+        const uint32_t c = have_carry ? carry[w] : 0u;
+        if (n <= 1) {
+          bit[l][w] = a | c;
+          carry[w] = 0;
+        } else if (n == 2) {
+          const uint32_t y = fill[l] >= 2 ? b : c;
+          bit[l][w] = a ^ y;
+          carry[w] = a & y;
+        } else {
+          bit[l][w] = bitop3<kTT_Xor3>(a, b, c);
+          carry[w] = bitop3<kTT_Maj>(a, b, c);
+        }
+      }
+      have_carry = n >= 2;
+    }
+    if (have_carry) {
+#pragma unroll
+      for (int w = 0; w < NWW; ++w) over[w] |= carry[w];
+    }
+  }
+};
+
+// n_cand: only windows 0 .. n_cand-1 are ever looked at (the read length is part of the specialisation), so a window
+// word may hold junk above them -- which lets the last window word of most positions be a plain shift.
+template <int NW, int NWW, int NB, bool kAnyX>
+BC_HD void count_mismatches_static(const DevPlan& pl, const Planes<NW>& P, uint32_t n_cand, Counters<NWW, NB>& C) {
+  constexpr int kLevels = 9;  // counts below 512: more constant positions than a 320-base read can hold
+  CsaCounter<NWW, kLevels> acc;
+  acc.init();
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (pl.n_pos[c] == 0) continue;
+    // u = "base is neither letter c nor 'N'": the mismatch indicator (N is free, parse.rs:569); zero past the read's
+    // words, and whatever the padding bytes give inside the last word -- only windows inside the read are candidates
+    uint32_t u[NW + NWW + 1];
+#pragma unroll
+    for (int w = 0; w < NW + NWW + 1; ++w) {
+      if (w >= NW) {
+        u[w] = 0;
+        continue;
+      }
+      // the complement of f(p1, p2, pn) = pn | (p1 == c1 & p2 == c2)
+      u[w] = c == 0 ? bitop3<0xFF ^ 0xAB>(P.p1[w], P.p2[w], P.pn[w])
+           : c == 1 ? bitop3<0xFF ^ 0xBA>(P.p1[w], P.p2[w], P.pn[w])
+           : c == 2 ? bitop3<0xFF ^ 0xAE>(P.p1[w], P.p2[w], P.pn[w])
+                    : bitop3<0xFF ^ 0xEA>(P.p1[w], P.p2[w], P.pn[w]);
+      if (kAnyX) u[w] |= P.px[w];  // a foreign byte never matches
+    }
+    for_each_position(pl, c, [&](uint32_t pos) {
+      const uint32_t k = pos >> 5, sh = pos & 31u;
+      uint32_t x[NWW];
+      if (sh == 0u) {
+#pragma unroll
+        for (int w = 0; w < NWW; ++w) x[w] = u[k + w];
+      } else if (NWW == 1 && sh + n_cand <= 32u) {
+        x[0] = u[k] >> sh;
+      } else if (NWW == 2 && sh + n_cand <= 64u) {
+        x[0] = alignbit(u[k + 1], u[k], sh);
+        x[1] = u[k + 1] >> sh;  // its top sh bits are junk no candidate window sees: a plain shift will do
+      } else {
+#pragma unroll
+        for (int w = 0; w < NWW; ++w) x[w] = alignbit(u[k + w + 1], u[k + w], sh);
+      }
+      acc.add(x);
+    });
+  }
+  uint32_t bit[kLevels][NWW];
+  acc.finish(bit);
+#pragma unroll
+  for (int w = 0; w < NWW; ++w) {
+    C.ovf[w] = acc.over[w];
+#pragma unroll
+    for (int l = 0; l < kLevels; ++l) {
+      if (l < NB)
+        C.cnt[l][w] = bit[l][w];
+      else
+        C.ovf[w] |= bit[l][w];
+    }
+    if (NB == 0) C.cnt[0][w] = 0;
+  }
+}
+
 // AND of the class vector over the class's positions, for every window (scheme-N positions)
 template <int NW, int NWW>
 BC_HD void and_program(const DevPlan& pl, int c, uint32_t (&v)[NW], uint32_t (&acc)[NWW]) {
@@ -352,12 +555,21 @@ BC_HD void and_program(const DevPlan& pl, int c, uint32_t (&v)[NW], uint32_t (&a
 //  * otherwise fix_constant_region (parse.rs:287-313): among the windows 0 .. len-L-1 (the last
 //    window is never tested, parse.rs:291-295) the unique minimum-mismatch window within the
 //    budget (fix_error, parse.rs:577-592), provided its scheme-N positions are valid bases.
-template <class Ops, int NW, int NWW, int NB>
+// kAnyX: some lane of the wave holds a byte outside ACGTN (a separate, rarely run instantiation, so that the common
+// one carries no trace of the px plane)
+template <class Ops, int NW, int NWW, int NB, bool kAnyX>
 BC_HD bool locate(const DevPlan& pl, Ops& ops, const Planes<NW>& P, const uint32_t (&inr)[NW], uint32_t len, bool live,
-                  bool anyx, uint32_t& start, bool& repaired) {
+                  uint32_t& start, bool& repaired) {
   const uint32_t L = pl.L;
   Counters<NWW, NB> C;
-  count_mismatches<NW, NWW, NB>(pl, P, anyx, C);
+  // BC_NO_STATIC_COUNT: the engine's second try for a scheme whose straight-line form the compiler did not manage
+  // to keep in registers (bc_engine.hip jit_function)
+#if (defined(BC_JIT_TU) || defined(BC_EMU_STATIC_COUNT)) && !defined(BC_NO_STATIC_COUNT)
+  // candidate windows of this kernel's batch shape: 0 .. read_len - L for fixed-length reads, any window otherwise
+  count_mismatches_static<NW, NWW, NB, kAnyX>(pl, P, BC_STATIC_CAND(L, NWW), C);
+#else
+  count_mismatches<NW, NWW, NB, kAnyX>(pl, P, C);
+#endif
 
   uint32_t fnok[NWW];
 #pragma unroll
@@ -365,7 +577,7 @@ BC_HD bool locate(const DevPlan& pl, Ops& ops, const Planes<NW>& P, const uint32
   if (pl.has_fmtn) {  // [AGCT]{n}, info.rs:291-294
     uint32_t v[NW];
 #pragma unroll
-    for (int w = 0; w < NW; ++w) v[w] = inr[w] & ~(P.pn[w] | P.px[w]);
+    for (int w = 0; w < NW; ++w) v[w] = kAnyX ? (inr[w] & ~(P.pn[w] | P.px[w])) : (inr[w] & ~P.pn[w]);
     and_program<NW, NWW>(pl, kClassFmtN, v, fnok);
   }
 
@@ -457,6 +669,17 @@ BC_HD bool locate(const DevPlan& pl, Ops& ops, const Planes<NW>& P, const uint32
   return found;
 }
 
+// counter width is a compile-time constant; any width whose range covers max_const (or none at all when no mismatch
+// is allowed) gives the same verdicts
+template <class Ops, int NW, int NWW, bool kAnyX>
+BC_HD bool locate_nb(const DevPlan& pl, Ops& ops, const Planes<NW>& P, const uint32_t (&inr)[NW], uint32_t len, bool live,
+                     uint32_t& start, bool& repaired) {
+  if (pl.max_const == 0u) return locate<Ops, NW, NWW, 0, kAnyX>(pl, ops, P, inr, len, live, start, repaired);
+  if (pl.nb <= 2u) return locate<Ops, NW, NWW, 2, kAnyX>(pl, ops, P, inr, len, live, start, repaired);
+  if (pl.nb == 3u) return locate<Ops, NW, NWW, 3, kAnyX>(pl, ops, P, inr, len, live, start, repaired);
+  return locate<Ops, NW, NWW, 5, kAnyX>(pl, ops, P, inr, len, live, start, repaired);
+}
+
 // ---- quality (RawSequenceRead::low_quality, parse.rs:331-375) ----------------------------------
 // sum of (byte - 33) mod 256 over `len` bytes starting at byte address `addr` of the quality tile
 BC_HD uint32_t score_sum(const uint32_t* q32, uint32_t addr, uint32_t len) {
@@ -475,6 +698,30 @@ BC_HD uint32_t score_sum(const uint32_t* q32, uint32_t addr, uint32_t len) {
     sum = sad_u8(d, 0u, sum);
   }
   return sum;
+}
+
+// The same sum for the common case that no byte is below '!' (33), in two v_sad_u8 per dword: sum |b - 33| equals
+// sum (b - 33) exactly when every b >= 33, and is larger otherwise -- so ok = false tells the caller to take score_sum
+// (bytes below 33 wrap in the reference's release build, parse.rs:326; a well-formed FASTQ has none).
+BC_HD uint32_t score_sum_fast(const uint32_t* q32, uint32_t addr, uint32_t len, bool& ok) {
+  const uint32_t a = addr & 3u;
+  const uint32_t k0 = addr >> 2;
+  const uint32_t nd = (len + 3u) >> 2;  // wave-uniform
+  uint32_t prev = q32[k0];
+  uint32_t s_abs = 0, s_raw = 0;
+  for (uint32_t j = 0; j < nd; ++j) {
+    const uint32_t nxt = q32[k0 + j + 1];
+    uint32_t d = alignbyte(nxt, prev, a);
+    prev = nxt;
+    if (j == nd - 1 && (len & 3u)) {  // bytes past the run count as '!' = score 0
+      const uint32_t m = lowmask(8u * (len & 3u));
+      d = (d & m) | (0x21212121u & ~m);
+    }
+    s_abs = sad_u8(d, 0x21212121u, s_abs);
+    s_raw = sad_u8(d, 0u, s_raw);
+  }
+  ok = s_raw == s_abs + 33u * 4u * nd;
+  return s_abs;
 }
 
 // ---- distance of a capture to one reference (the inner loop of fix_error, parse.rs:562-575) ----
@@ -716,9 +963,11 @@ struct ReadResult {
 //                                                   on: returns where the quality lines are; n = loads of its
 //                                                   own the lane code still has in flight
 // NW = 32-base words per read; NWW = words of candidate offsets / repair windows (len - L + 1 <= 32*NWW)
-template <class Ops, int NW, int NWW>
+// kAligned: base is a multiple of 4 for every lane (the stride is)
+template <class Ops, int NW, int NWW, bool kAligned = false>
+// len / qlen: length of the sequence line / of the quality line (they differ in trimmed or damaged files)
 BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32, uint32_t base, uint32_t len,
-                              uint32_t nd, bool active) {
+                              uint32_t qlen, uint32_t nd, bool active) {
   ReadResult res;
   res.outcome = kMatched;
   res.dense_idx = 0;
@@ -731,7 +980,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
 #pragma unroll
     for (int w = 0; w < NW; ++w) { P.p1[w] = base * 2654435761u + w; P.p2[w] = base * 40503u + w; P.pn[w] = 0; P.px[w] = 0; }
   } else {
-    pack_read<NW>(seq32, base, nd, P, bad);
+    pack_read<NW, kAligned>(seq32, base, nd, P, bad);
   }
   uint32_t inr[NW];
   low_bits<NW>(inr, len);
@@ -762,14 +1011,10 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
     // at all when no mismatch is allowed) gives the same verdicts
     if (pl.abl() & 0x10u) {
       found = true;
-    } else if (pl.max_const == 0u) {
-      found = locate<Ops, NW, NWW, 0>(pl, ops, P, inr, len, live, anyx, start, repaired);
-    } else if (pl.nb <= 2u) {
-      found = locate<Ops, NW, NWW, 2>(pl, ops, P, inr, len, live, anyx, start, repaired);
-    } else if (pl.nb == 3u) {
-      found = locate<Ops, NW, NWW, 3>(pl, ops, P, inr, len, live, anyx, start, repaired);
+    } else if (anyx) {
+      found = locate_nb<Ops, NW, NWW, true>(pl, ops, P, inr, len, live, start, repaired);
     } else {
-      found = locate<Ops, NW, NWW, 5>(pl, ops, P, inr, len, live, anyx, start, repaired);
+      found = locate_nb<Ops, NW, NWW, false>(pl, ops, P, inr, len, live, start, repaired);
     }
   }
 
@@ -792,15 +1037,27 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
       ops.mark(4);
       // after a repair the quality line is read from offset 0
       const uint32_t qstart = repaired ? 0u : start_found;
-      const uint32_t avail = len - qstart;  // quality line assumed as long as the sequence line
+      // scores.iter().skip(start).zip(regions) (parse.rs:340-345): what is left of the QUALITY line after the skip
+      const uint32_t avail = qlen > qstart ? qlen - qstart : 0u;
       const uint32_t zip = avail < pl.RL ? avail : pl.RL;
-      bool low = false;
+      bool low = false, plain = true;
       for (uint32_t r = 0; r < pl.n_runs; ++r) {
         const uint32_t ro = pl.run_off[r], rl = pl.run_len[r];
         // a run is only evaluated when the zip continues past it (parse.rs:348-356)
         const bool evaluated = (ro + rl) < zip;
-        const uint32_t sum = score_sum(qual32, base + (found ? qstart : 0u) + ro, rl);
+        bool ok;
+        const uint32_t sum = score_sum_fast(qual32, base + (found ? qstart : 0u) + ro, rl, ok);
+        plain = plain && ok;
         low = low || (evaluated && sum < pl.run_thr[r]);
+      }
+      if (ops.any(!plain)) {  // some quality byte below '!': the wrapping form, every run again
+        low = false;
+        for (uint32_t r = 0; r < pl.n_runs; ++r) {
+          const uint32_t ro = pl.run_off[r], rl = pl.run_len[r];
+          const bool evaluated = (ro + rl) < zip;
+          const uint32_t sum = score_sum(qual32, base + (found ? qstart : 0u) + ro, rl);
+          low = low || (evaluated && sum < pl.run_thr[r]);
+        }
       }
       if (outcome == kMatched && low) outcome = kLowQuality;  // parse.rs:111
     }

@@ -162,6 +162,24 @@ NO_RANDOM_CASES = [c for c in ALL_CASES if c not in RANDOM_CASES]
 RANDOM_ENGINE_CASES = list(RANDOM_CASES) + ["rnd_rb_%d" % i for i in range(8)]
 
 
+def with_wrapping_quality(c, seed=0, frac=0.3):
+    """quality bytes below '!' (33) in a share of the reads: `ch as u8 - 33` wraps in the reference's release build
+    (parse.rs:326), so such a byte scores 223..255 -- the engine's two-v_sad_u8 fast path must notice and defer to the
+    wrapping form"""
+    import numpy as np
+    rng = np.random.default_rng(1000 + seed)
+    out = []
+    for s, q in c["reads"]:
+        if rng.random() < frac and len(q) > 4:
+            q = list(q)
+            for _ in range(int(rng.integers(1, 6))):
+                q[int(rng.integers(0, len(q)))] = chr(int(rng.integers(1, 33)))
+            q = "".join(q)
+        out.append((s, q))
+    c["reads"] = out
+    return c
+
+
 def random_case(seed, n=300, with_random=False):
     """A randomly drawn scheme (constants with the odd N, optional sample group, 1-4 counted groups of 3-20
     bases), random set sizes / budgets / quality threshold, conversion files present or not: the shapes the

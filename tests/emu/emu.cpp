@@ -43,23 +43,27 @@ struct EmuPlan {
 };
 
 template <int NW, int NWW>
-void run(const EmuPlan& E, const uint8_t* seq, const uint8_t* qual, const uint16_t* lens, uint32_t stride,
+void run(const EmuPlan& E, const uint8_t* seq, const uint8_t* qual, const uint16_t* lens, const uint16_t* qlens, uint32_t stride,
          uint32_t read_len, uint64_t n, uint8_t* outcomes, uint64_t* idx, uint64_t* rcode) {
   const uint32_t maxlen = lens ? stride : read_len;
   const uint32_t nd = (maxlen + 3) / 4;
   HostOps ops;
   std::vector<uint32_t> s32((stride + 512) / 4 + 4), q32((stride + 512) / 4 + 4);
   for (uint64_t i = 0; i < n; ++i) {
-    // place the read at a rotating byte misalignment to exercise the alignbyte path
-    const uint32_t base = (uint32_t)(i & 3);
+    // place the read at a rotating byte misalignment to exercise the alignbyte path; every other group of four
+    // reads sits on a dword boundary and goes through the instantiation that knows it (kAligned)
+    const bool aligned = (i & 4) != 0;
+    const uint32_t base = aligned ? 4u * (uint32_t)(i & 3) : (uint32_t)(i & 3);
     memset(s32.data(), 'A', s32.size() * 4);
     memset(q32.data(), 'I', q32.size() * 4);
     memcpy((uint8_t*)s32.data() + base, seq + i * stride, stride);
     if (qual) memcpy((uint8_t*)q32.data() + base, qual + i * stride, stride);
     const uint32_t len = lens ? lens[i] : read_len;
+    const uint32_t qlen = qlens ? qlens[i] : len;
     ops.qual32 = q32.data();
     ops.area = reinterpret_cast<const bc::Quad*>(E.lhash.data());
-    bc::ReadResult r = bc::process_read<HostOps, NW, NWW>(E.h.plan, ops, s32.data(), base, len, nd, true);
+    bc::ReadResult r = aligned ? bc::process_read<HostOps, NW, NWW, true>(E.h.plan, ops, s32.data(), base, len, qlen, nd, true)
+                               : bc::process_read<HostOps, NW, NWW, false>(E.h.plan, ops, s32.data(), base, len, qlen, nd, true);
     outcomes[i] = (uint8_t)r.outcome;
     idx[i] = r.dense_idx;
     if (rcode) rcode[i] = r.rcode;
@@ -108,13 +112,13 @@ uint64_t emu_table_entries(void* e) { return ((EmuPlan*)e)->h.table_entries; }
 int emu_discard_counts(void* e) { return (int)((EmuPlan*)e)->h.plan.discard_counts; }
 uint64_t emu_rspace(void* e) { return ((EmuPlan*)e)->h.plan.has_random ? ((EmuPlan*)e)->h.plan.rspace : 0; }
 
-int emu_process(void* e, const uint8_t* seq, const uint8_t* qual, const uint16_t* lens, uint32_t stride,
-                uint32_t read_len, uint64_t n, uint8_t* outcomes, uint64_t* idx, uint64_t* rcode) {
+int emu_process2(void* e, const uint8_t* seq, const uint8_t* qual, const uint16_t* lens, const uint16_t* qlens, uint32_t stride,
+                 uint32_t read_len, uint64_t n, uint8_t* outcomes, uint64_t* idx, uint64_t* rcode) {
   const EmuPlan& E = *(EmuPlan*)e;
   const uint32_t maxlen = lens ? stride : read_len;
   const uint32_t L = E.h.plan.L;
   const uint32_t nww = maxlen >= L ? (maxlen - L + 1 + 31) / 32 : 1;
-#define EMU_RUN(NW_, NWW_) run<NW_, NWW_>(E, seq, qual, lens, stride, read_len, n, outcomes, idx, rcode)
+#define EMU_RUN(NW_, NWW_) run<NW_, NWW_>(E, seq, qual, lens, qlens, stride, read_len, n, outcomes, idx, rcode)
   if (maxlen <= 128) {
     if (nww <= 1) EMU_RUN(4, 1); else if (nww <= 2) EMU_RUN(4, 2); else EMU_RUN(4, 4);
   } else if (maxlen <= 256) {
@@ -126,5 +130,10 @@ int emu_process(void* e, const uint8_t* seq, const uint8_t* qual, const uint16_t
   }
 #undef EMU_RUN
   return 0;
+}
+
+int emu_process(void* e, const uint8_t* seq, const uint8_t* qual, const uint16_t* lens, uint32_t stride,
+                uint32_t read_len, uint64_t n, uint8_t* outcomes, uint64_t* idx, uint64_t* rcode) {
+  return emu_process2(e, seq, qual, lens, nullptr, stride, read_len, n, outcomes, idx, rcode);
 }
 }

@@ -9,20 +9,23 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "ngs-barcode-count_amd", "csrc")
 SO = os.path.join(ROOT, "tests", "emu", "libbc_emu.so")
+# "static": the lane code compiled with the counting form of the scheme-specialised kernels (carry-save accumulation of
+# directly extracted windows, bc_lane.h count_mismatches_static), which otherwise only a GPU build would exercise
+VARIANTS = {"generic": (SO, []), "static": (SO.replace(".so", "_static.so"), ["-DBC_EMU_STATIC_COUNT=1"])}
 SRCS = [os.path.join(ROOT, "tests", "emu", "emu.cpp"), os.path.join(CSRC, "bc_plan.cpp")]
 DEPS = SRCS + [os.path.join(CSRC, f) for f in ("bc_lane.h", "bc_intrin.h", "bc_device_plan.h", "bc_plan.hpp")]
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in DEPS):
+def lib(variant="generic"):
+    if variant not in _libs:
+        so, flags = VARIANTS[variant]
+        if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in DEPS):
             subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Wno-unknown-pragmas", "-fPIC", "-shared",
-                                   "-o", SO] + SRCS)
+                                   "-o", so] + flags + SRCS)
         import ngs_barcode_count_amd as pkg
-        L = C.CDLL(SO)
+        L = C.CDLL(so)
         pkg._lib.declare(L, pkg._lib.PLAN_API)
         L.emu_plan_create.restype = C.c_void_p
         L.emu_plan_create.argtypes = [C.c_void_p]
@@ -31,16 +34,17 @@ def lib():
         L.emu_table_entries.argtypes = [C.c_void_p]
         L.emu_discard_counts.argtypes = [C.c_void_p]
         L.emu_process.argtypes = [C.c_void_p] * 4 + [C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.emu_process2.argtypes = [C.c_void_p] * 5 + [C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.emu_rspace.restype = C.c_uint64
         L.emu_rspace.argtypes = [C.c_void_p]
-        _lib = L
-    return _lib
+        _libs[variant] = L
+    return _libs[variant]
 
 
-def make_plan(case):
+def make_plan(case, variant="generic"):
     """Plan (host-only functions, served by the emu library) for a cases.build_case() dict"""
     import ngs_barcode_count_amd as pkg
-    p = pkg.Plan(case["scheme"], lib=lib())
+    p = pkg.Plan(case["scheme"], lib=lib(variant))
     if case.get("samples"):
         for s, i in case["samples"].items():
             p.add_sample(s, i)
@@ -54,10 +58,10 @@ def make_plan(case):
     return p
 
 
-def emulate(plan, seq, qual, lens, stride, read_len, with_random=False):
+def emulate(plan, seq, qual, lens, stride, read_len, with_random=False, qlens=None):
     """-> (outcomes, dense idx, table entries, discard flag); with_random adds (rcode, rspace): in
     random-barcode mode outcome 0 means "passed every test" -- set membership is the caller's job"""
-    L = lib()
+    L = plan._lib  # the emu variant the plan was made with
     e = L.emu_plan_create(plan._p)
     if not e:
         raise RuntimeError(L.bc_last_error().decode())
@@ -65,9 +69,9 @@ def emulate(plan, seq, qual, lens, stride, read_len, with_random=False):
     outc = np.zeros(n, dtype=np.uint8)
     idx = np.zeros(n, dtype=np.uint64)
     rcode = np.zeros(n, dtype=np.uint64)
-    rc = L.emu_process(e, seq.ctypes.data, qual.ctypes.data if qual is not None else None,
-                       lens.ctypes.data if lens is not None else None, stride, read_len, n, outc.ctypes.data,
-                       idx.ctypes.data, rcode.ctypes.data)
+    rc = L.emu_process2(e, seq.ctypes.data, qual.ctypes.data if qual is not None else None,
+                        lens.ctypes.data if lens is not None else None, qlens.ctypes.data if qlens is not None else None,
+                        stride, read_len, n, outc.ctypes.data, idx.ctypes.data, rcode.ctypes.data)
     entries = L.emu_table_entries(e)
     discard = L.emu_discard_counts(e)
     rspace = L.emu_rspace(e)

@@ -210,6 +210,106 @@ def test_key_export_import_roundtrip():
     e2.close()
 
 
+def test_random_barcode_multi_rank_flow_with_real_engines():
+    """the documented multi-GPU flow of a dense plan with a random barcode -- key exchange, then a sum
+    of tables, then finish on the root -- driven through REAL engines: two engines stand for two ranks (each counted
+    its own shard), keys go to their owner (distributed.key_owner), every rank materializes the distinct counts of the
+    keys it owns, the tables are added onto rank 0 and rank 0's finish compacts that sum as it stands.  Rows and
+    counters must equal the oracle's over all reads."""
+    import torch
+    pkg = _pkg()
+    from ngs_barcode_count_amd import distributed as bcdist
+    c = cases.build_case("del_random", seed=41, n=6000)
+    plan = make_plan(c)
+    assert plan.mode == "dense"
+    seq, qual, lens = readgen.to_arrays(c["reads"])
+    stride = seq.shape[1]
+    half = len(c["reads"]) // 2
+    world = 2
+    tables = [torch.zeros(plan.table_entries, dtype=torch.int32, device="cuda") for _ in range(world)]
+    torch.cuda.synchronize()
+    engs, local = [], []
+    for r in range(world):
+        a, b = (0, half) if r == 0 else (half, len(c["reads"]))
+        e = pkg.Engine(plan, device=0, table_ptr=tables[r].data_ptr())
+        e.submit_host(seq[a:b].reshape(-1), qual[a:b].reshape(-1), stride, stride, lens[a:b])
+        engs.append(e)
+        local.append(e.counters())
+    # the exchange: every key to its owner rank
+    outbox = [[None] * world for _ in range(world)]
+    for r, e in enumerate(engs):
+        n = e.key_count()
+        buf = torch.zeros(max(n, 1), dtype=torch.int64, device="cuda")
+        e.export_keys(buf.data_ptr(), n)
+        owner = bcdist.key_owner(buf[:n], world)
+        for d in range(world):
+            outbox[r][d] = buf[:n][owner == d].contiguous()
+    total = dict.fromkeys(pkg.COUNTER_NAMES, 0)
+    for r, e in enumerate(engs):
+        recv = torch.cat([outbox[src][r] for src in range(world)])
+        torch.cuda.synchronize()
+        e.clear_keys()
+        owned = e.import_keys(recv.data_ptr(), recv.numel()) if recv.numel() else 0
+        fixed = dict(local[r])
+        fixed["duplicates"] = local[r]["duplicates"] + local[r]["matched"] - owned
+        fixed["matched"] = owned
+        for k in total:
+            total[k] += fixed[k]
+        e.materialize_table()
+    # a sum of zero tables (what the flow did before materialize existed) would give no rows at all
+    assert int(tables[1].sum()) > 0
+    tables[0] += tables[1]
+    torch.cuda.synchronize()
+    o = parity.oracle_for(c)
+    for sq, ql in c["reads"]:
+        o.process(sq, ql)
+    assert engs[0].result_rows() == o.rows()
+    assert {k: total[k] for k in o.counters} == o.counters and o.counters["duplicates"] > 0
+    # a later submit invalidates the materialized table: finish then rebuilds it from the engine's own keys
+    engs[1].submit_host(seq[:10].reshape(-1), qual[:10].reshape(-1), stride, stride, lens[:10])
+    assert sum(cnt for _, _, cnt in engs[1].result_rows()) == engs[1].key_count()
+    for e in engs:
+        e.close()
+
+
+@pytest.mark.parametrize("kernel", ["generic", "specialised"], indirect=True)
+def test_quality_bytes_below_33_wrap_like_the_reference(kernel):
+    """`ch as u8 - 33` wraps for bytes below '!' (parse.rs:326): the kernel's fast quality sums must defer to the
+    wrapping form whenever such a byte is in a run"""
+    c = cases.with_wrapping_quality(cases.build_case("del_mismatch_quality", seed=23, n=3000), seed=2)
+    plan = make_plan(c)
+    seq, qual, lens = readgen.to_arrays(c["reads"])
+    eng, outc, idx = run_device(plan, seq, qual, lens, seq.shape[1], seq.shape[1])
+    o = parity.check_per_read(c, plan, outc, idx, False)
+    got = eng.counters()
+    assert {k: got[k] for k in o.counters} == o.counters and o.counters["low_quality"] > 0
+    check_kernel(eng, kernel)
+    eng.close()
+
+
+def test_release_library_ignores_experiment_switches(monkeypatch, tmp_path):
+    """an environment variable must not be able to make the counting tool miscount.  BC_ABLATE (phases
+    skipped), BC_LHASH / BC_PIPE (kernel variants) are honoured only by -DBC_EXPERIMENT builds."""
+    monkeypatch.setenv("BC_ABLATE", "0xffff")
+    monkeypatch.setenv("BC_LHASH", "0")
+    monkeypatch.setenv("BC_PIPE", "0")
+    monkeypatch.setenv("BC_JIT_FLAGS", "-DBC_MIN_WAVES=1")
+    monkeypatch.setenv("BC_JIT", "force")
+    monkeypatch.setenv("BC_JIT_CACHE", str(tmp_path / "jit_cache"))
+    c = cases.build_case("del_mismatch_quality", seed=5, n=4000)
+    plan = make_plan(c)
+    seq, qual, lens = readgen.to_arrays(c["reads"])
+    eng, outc, idx = run_device(plan, seq, qual, lens, seq.shape[1], seq.shape[1])
+    assert eng.kernel_name().startswith("bc_jit_match_count")
+    o = parity.oracle_for(c)
+    for sq, ql in c["reads"]:
+        o.process(sq, ql)
+    got = eng.counters()
+    assert {k: got[k] for k in o.counters} == o.counters
+    assert eng.result_rows() == o.rows()
+    eng.close()
+
+
 def test_kat_reads_on_device():
     """Appendix B K1-K7b (anchor, exclusive last window, N-free repair, quality offset after repair),
     the example scheme verbatim (with its random barcode), known sets holding the KAT captures"""

@@ -13,15 +13,21 @@ import readgen
 NO_RANDOM = cases.NO_RANDOM_CASES
 
 
+# "static": the counting form of the scheme-specialised kernels (bc_lane.h count_mismatches_static) compiled into the
+# emulation, so that it is checked here too and not only on the GPU
+VARIANTS = ["generic", "static"]
+
+
 @pytest.mark.parametrize("name", NO_RANDOM)
 @pytest.mark.parametrize("use_lens", [False, True])
-def test_lane_code_vs_oracle(name, use_lens):
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_lane_code_vs_oracle(name, use_lens, variant):
     c = cases.build_case(name, seed=3 + use_lens, n=500)
     if not use_lens:
         # uniform length: truncate / drop so every read has the same length
         rl = min(len(s) for s, _ in c["reads"])
         c["reads"] = [(s[:rl], q[:rl]) for s, q in c["reads"]]
-    plan = emu_lib.make_plan(c)
+    plan = emu_lib.make_plan(c, variant)
     seq, qual, lens = readgen.to_arrays(c["reads"])
     stride = seq.shape[1]
     outc, idx, entries, discard = emu_lib.emulate(plan, seq.reshape(-1), qual.reshape(-1), lens if use_lens else None,
@@ -29,11 +35,23 @@ def test_lane_code_vs_oracle(name, use_lens):
     parity.check_per_read(c, plan, outc, idx, discard)
 
 
+@pytest.mark.parametrize("name", ["del_mismatch_quality", "raw_counted", "long_gaps"])
+def test_quality_bytes_below_33_wrap_like_the_reference(name):
+    c = cases.with_wrapping_quality(cases.build_case(name, seed=17, n=600), seed=1)
+    plan = emu_lib.make_plan(c)
+    seq, qual, lens = readgen.to_arrays(c["reads"])
+    stride = seq.shape[1]
+    outc, idx, entries, discard = emu_lib.emulate(plan, seq.reshape(-1), qual.reshape(-1), lens, stride, stride)
+    o = parity.check_per_read(c, plan, outc, idx, discard)
+    assert o.counters["low_quality"] > 0 and o.counters["matched"] > 0
+
+
 @pytest.mark.parametrize("seed", range(40))
-def test_randomly_drawn_schemes(seed):
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_randomly_drawn_schemes(seed, variant):
     """schemes, sets, budgets and thresholds drawn at random (cases.random_case): lane code vs oracle"""
     c = cases.random_case(seed, n=300)
-    plan = emu_lib.make_plan(c)
+    plan = emu_lib.make_plan(c, variant)
     seq, qual, lens = readgen.to_arrays(c["reads"])
     stride = seq.shape[1]
     outc, idx, entries, discard = emu_lib.emulate(plan, seq.reshape(-1), qual.reshape(-1), lens, stride, stride)
@@ -56,13 +74,14 @@ def test_random_barcode_keys_vs_oracle(name):
     assert name == "example_files_samples" or name.startswith("rnd_rb_") or o.counters["duplicates"] > 0
 
 
-def test_long_reads_use_wider_planes():
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_long_reads_use_wider_planes(variant):
     for rl in (150, 250, 300):
         c = cases.build_case("del_mismatch_quality", seed=rl, n=60)
         rng = np.random.default_rng(rl)
         c["reads"] = readgen.gen_reads(rng, c["scheme"], 200, rl, list(c["samples"]), c["counted"], p_sub=0.02,
                                        p_n=0.004)
-        plan = emu_lib.make_plan(c)
+        plan = emu_lib.make_plan(c, variant)
         seq, qual, lens = readgen.to_arrays(c["reads"])
         outc, idx, entries, discard = emu_lib.emulate(plan, seq.reshape(-1), qual.reshape(-1), None, rl, rl)
         parity.check_per_read(c, plan, outc, idx, discard)
