@@ -168,3 +168,85 @@ def test_count_fastq_through_the_abi(tmp_path):
     assert e2.counters()["total_reads"] == len(c["reads"])
     eng.close()
     e2.close()
+
+
+def _count_file(plan, path):
+    import ngs_barcode_count_amd as pkg
+    eng = pkg.Engine(plan, device=0)
+    total = eng.count_fastq(path)
+    got, rows = eng.counters(), eng.result_rows()
+    eng.close()
+    return total, got, rows
+
+
+@pytest.mark.parametrize("chunk", [4096, 4112, 65536])
+@pytest.mark.parametrize("name", ["del_mismatch_quality", "fmtn"])
+def test_records_straddling_ingest_chunks(tmp_path, monkeypatch, chunk, name):
+    """the device-side framing: chunks are arbitrary byte ranges of the file, so with 4 KiB chunks nearly every chunk
+    boundary falls inside a record; headers of varying length move the boundaries around"""
+    from test_gpu_parity import make_plan
+    monkeypatch.setenv("BC_INGEST_CHUNK", str(chunk))
+    c = cases.build_case(name, seed=51, n=1200)
+    fq = os.path.join(str(tmp_path), "reads.fastq")
+    with open(fq, "w") as f:
+        for i, (s, q) in enumerate(c["reads"]):
+            f.write("@r%d %s\n%s\n+%s\n%s\n" % (i, "x" * (i % 37), s, "same" * (i % 3), q))
+    o = parity.oracle_for(c)
+    for s, q in c["reads"]:
+        o.process(s, q)
+    total, got, rows = _count_file(make_plan(c), fq)
+    assert total == len(c["reads"]) and got["total_reads"] == len(c["reads"])
+    assert {k: got[k] for k in o.counters} == o.counters and rows == o.rows()
+
+
+def test_file_sizes_around_a_chunk_multiple_and_missing_final_newline(tmp_path, monkeypatch):
+    """end-of-file accounting (input.rs:44, 86, 128-130): a last record without its final newline is a whole record on
+    the plain path; file lengths just below, at and just above a multiple of the chunk size"""
+    from test_gpu_parity import make_plan
+    monkeypatch.setenv("BC_INGEST_CHUNK", "4096")
+    c = cases.build_case("del_exact", seed=52, n=400)
+    plan = make_plan(c)
+    text = "".join("@r%d\n%s\n+\n%s\n" % (i, s, q) for i, (s, q) in enumerate(c["reads"]))
+    o = parity.oracle_for(c)
+    for s, q in c["reads"]:
+        o.process(s, q)
+    for variant, cut in (("exact", 0), ("no_final_newline", 1)):
+        body = text[:len(text) - cut]
+        for pad in (-1, 0, 1):
+            # pad the FIRST header so that the file is `pad` bytes off a multiple of the chunk size
+            want = ((len(body) + 4095) // 4096) * 4096 + 4096 + pad
+            t2 = "@" + "h" * (want - len(body)) + body[1:]
+            assert len(t2) == want + 0
+            fq = os.path.join(str(tmp_path), "%s_%d.fastq" % (variant, pad + 1))
+            open(fq, "w").write(t2)
+            total, got, rows = _count_file(plan, fq)
+            assert total == len(c["reads"]), (variant, pad, total)
+            assert {k: got[k] for k in o.counters} == o.counters and rows == o.rows(), (variant, pad)
+
+
+def test_quality_line_of_another_length_than_the_sequence_line(tmp_path):
+    """trimmed or damaged FASTQ files have records whose quality line is shorter (or longer) than the
+    sequence line; the reference zips scores with regions (parse.rs:340-345), the engine used to refuse the file"""
+    from test_gpu_parity import make_plan
+    rng = np.random.default_rng(77)
+    c = cases.build_case("del_mismatch_quality", seed=53, n=1500)
+    reads = []
+    for s, q in c["reads"]:
+        r = rng.random()
+        if r < 0.2:
+            q = q[:int(rng.integers(0, len(q)))]          # truncated quality line
+        elif r < 0.3:
+            q = q + "I" * int(rng.integers(1, 30))         # longer than the sequence line
+        reads.append((s, q))
+    c["reads"] = reads
+    fq = os.path.join(str(tmp_path), "reads.fastq")
+    with open(fq, "w") as f:
+        for i, (s, q) in enumerate(reads):
+            f.write("@r%d\n%s\n+\n%s\n" % (i, s, q))
+    o = parity.oracle_for(c)
+    for s, q in reads:
+        o.process(s, q)
+    total, got, rows = _count_file(make_plan(c), fq)
+    assert total == len(reads)
+    assert {k: got[k] for k in o.counters} == o.counters and rows == o.rows()
+    assert o.counters["low_quality"] > 0 and o.counters["matched"] > 0

@@ -163,3 +163,33 @@ def test_foreign_byte_in_a_raw_capture_only_matters_for_counted_reads():
     exp = [o.process(s, qq) for s, qq in c["reads"]]
     assert exp == ["matched", "barcode", "matched"]
     assert [int(v) for v in outc] == [7, parity.CODE["barcode"], parity.CODE["matched"]]
+
+
+def test_quality_line_of_another_length_than_the_sequence_line():
+    """scores.iter().skip(start).zip(regions) (parse.rs:340-345): what counts is the quality line's own length"""
+    rng = np.random.default_rng(77)
+    c = cases.build_case("del_mismatch_quality", seed=53, n=800)
+    reads = []
+    for s, q in c["reads"]:
+        r = rng.random()
+        if r < 0.2:
+            q = q[:int(rng.integers(0, len(q)))]
+        elif r < 0.3:
+            q = q + "I" * int(rng.integers(1, 30))
+        reads.append((s, q))
+    c["reads"] = reads
+    plan = emu_lib.make_plan(c)
+    n = len(reads)
+    st = (max(len(s) for s, _ in reads) + 3) // 4 * 4
+    seq = np.full((n, st), ord("N"), dtype=np.uint8)
+    qual = np.full((n, st), ord("!"), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.uint16)
+    qlens = np.zeros(n, dtype=np.uint16)
+    for i, (s, q) in enumerate(reads):
+        seq[i, :len(s)] = np.frombuffer(s.encode(), dtype=np.uint8)
+        qq = q[:st]  # only the first `stride` quality bytes are stored; the length travels whole
+        qual[i, :len(qq)] = np.frombuffer(qq.encode(), dtype=np.uint8)
+        lens[i], qlens[i] = len(s), len(q)
+    outc, idx, entries, discard = emu_lib.emulate(plan, seq.reshape(-1), qual.reshape(-1), lens, st, st, qlens=qlens)
+    o = parity.check_per_read(c, plan, outc, idx, discard)
+    assert o.counters["low_quality"] > 0 and o.counters["matched"] > 0
