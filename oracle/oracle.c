@@ -1025,6 +1025,18 @@ void orc_process_batch(orc_ctx *c, const uint8_t *seq, const uint8_t *qual, cons
   }
 }
 
+/* the same, also reporting which counter each read bumped (exhaustive-domain tests compare read by read) */
+void orc_process_batch_outcomes(orc_ctx *c, const uint8_t *seq, const uint8_t *qual, const uint16_t *lens,
+                                const uint16_t *qlens, uint32_t stride, uint32_t read_len, uint64_t n, uint8_t *outcomes) {
+  for (uint64_t i = 0; i < n; i++) {
+    size_t l = lens ? lens[i] : read_len;
+    size_t ql = qlens ? qlens[i] : l;
+    const char *s = (const char *)seq + (size_t)i * stride;
+    const char *q = qual ? (const char *)qual + (size_t)i * stride : "";
+    outcomes[i] = (uint8_t)orc_process_read(c, s, l, q, qual ? ql : 0);
+  }
+}
+
 /* ------------------------------------------------------------------ */
 /* The reference's own thread structure, for the CPU baseline: one reader  */
 /* thread posting packed 4-line records to a mutex-guarded deque with the  */

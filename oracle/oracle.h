@@ -94,6 +94,11 @@ int orc_process_read(orc_ctx *c, const char *seq, size_t seqlen, const char *qua
 void orc_process_batch(orc_ctx *c, const uint8_t *seq, const uint8_t *qual, const uint16_t *lens, uint32_t stride,
                        uint32_t read_len, uint64_t n);
 
+/* orc_process_batch that also reports, per read, the counter index it incremented; qlens (may be NULL) gives quality
+ * lines a length of their own */
+void orc_process_batch_outcomes(orc_ctx *c, const uint8_t *seq, const uint8_t *qual, const uint16_t *lens,
+                                const uint16_t *qlens, uint32_t stride, uint32_t read_len, uint64_t n, uint8_t *outcomes);
+
 /* The same reads through the reference's own thread structure (bench.py's cpu_baseline): the calling thread is the
  * reader posting packed 4-line records to a mutex-guarded deque (10,000-record back-pressure spin,
  * src/input.rs:115-148), n_workers threads pop and match (busy spin while empty, src/parse.rs:53-86) on their own

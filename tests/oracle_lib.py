@@ -54,6 +54,8 @@ def lib():
         L.orc_process_read.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
         L.orc_process_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                         C.c_uint64]
+        L.orc_process_batch_outcomes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                                 C.c_uint32, C.c_uint64, C.c_void_p]
         L.orc_run_reference_threads.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_uint32, C.c_uint32, C.c_uint64]
         L.orc_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
@@ -197,6 +199,17 @@ class Oracle:
         n = seq.size // stride
         lib().orc_process_batch(self._c, seq.ctypes.data, qual.ctypes.data if qual is not None else None,
                                 lens.ctypes.data if lens is not None else None, stride, read_len, n)
+
+    def process_batch_outcomes(self, seq, qual, stride, read_len, lens=None, qlens=None):
+        """process_batch that also returns the per-read outcome codes (uint8 array, indices into NAMES)"""
+        import numpy as np
+        n = seq.size // stride
+        out = np.zeros(n, dtype=np.uint8)
+        lib().orc_process_batch_outcomes(self._c, seq.ctypes.data, qual.ctypes.data if qual is not None else None,
+                                         lens.ctypes.data if lens is not None else None,
+                                         qlens.ctypes.data if qlens is not None else None, stride, read_len, n,
+                                         out.ctypes.data)
+        return out
 
     @property
     def counters(self):

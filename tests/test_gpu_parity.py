@@ -397,3 +397,62 @@ def test_table_pack_kernel_matches_its_torch_form():
         back = b_gpu.to(torch.int32)
         back.index_add_(0, i_gpu, v_gpu)
         assert torch.equal(back.cpu(), t)
+
+
+@pytest.mark.parametrize("kernel", ["generic", "specialised"], indirect=True)
+def test_exhaustive_small_domain(kernel):
+    """tests/exhaustive.py on the GPU: EVERY read of up to 8 bases over {A,C,G,N} with EVERY quality string over two
+    symbols (19.2 M pairs), plus every 9-base read with eight quality strings -- each read's outcome and table index
+    against the oracle, through both kernels.  A proof over that domain, not a sample."""
+    import torch
+    import exhaustive
+    pkg = _pkg()
+    c = exhaustive.case()
+    plan = make_plan(c)
+    STRIDE = 12
+    eng = pkg.Engine(plan, device=0)
+    total = 0
+
+    def check(seq, qual, ln):
+        nonlocal total
+        n = seq.shape[0]
+        for a in range(0, n, 1 << 22):
+            b = min(n, a + (1 << 22))
+            s = np.ascontiguousarray(seq[a:b]).reshape(-1)
+            q = np.ascontiguousarray(qual[a:b]).reshape(-1)
+            lens = np.full(b - a, ln, dtype=np.uint16)
+            o = parity.oracle_for(c)
+            exp = o.process_batch_outcomes(s, q, STRIDE, STRIDE, lens=lens)
+            ds, dq = torch.from_numpy(s).cuda(), torch.from_numpy(q).cuda()
+            dl = torch.from_numpy(lens.view(np.int16)).cuda()
+            outc = torch.zeros(b - a, dtype=torch.uint8, device="cuda")
+            idx = torch.zeros(b - a, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            eng.reset()
+            eng.trace(outc.data_ptr(), idx.data_ptr())
+            eng.submit_device(ds.data_ptr(), dq.data_ptr(), b - a, STRIDE, STRIDE, dl.data_ptr())
+            eng.sync()
+            got = outc.cpu().numpy()
+            bad = np.nonzero(got != exp)[0]
+            assert bad.size == 0, (ln, bytes(seq[a + bad[0], :ln]), bytes(qual[a + bad[0], :ln]), int(got[bad[0]]),
+                                   int(exp[bad[0]]))
+            assert eng.result_rows() == o.rows(), ln
+            eng.trace(None, None)
+            total += b - a
+
+    for ln in range(0, 9):
+        seq, qual = exhaustive.domain(ln, STRIDE)
+        check(seq, qual, ln)
+    # nine bases: every read, eight quality strings (bit patterns of the quality index)
+    ln = 9
+    r = np.arange(4 ** ln, dtype=np.int64)
+    for qbits in (0, 0x1FF, 0x155, 0x0AA, 0x033, 0x1C7, 0x00F, 0x1F0):
+        seq = np.full((r.size, STRIDE), ord("N"), dtype=np.uint8)
+        qual = np.full((r.size, STRIDE), ord("!"), dtype=np.uint8)
+        for p in range(ln):
+            seq[:, p] = exhaustive.LETTERS[(r >> (2 * p)) & 3]
+            qual[:, p] = exhaustive.QUALS[(qbits >> p) & 1]
+        check(seq, qual, ln)
+    assert total == sum(8 ** k for k in range(9)) + 8 * 4 ** 9
+    check_kernel(eng, kernel)
+    eng.close()

@@ -96,6 +96,34 @@ def test_full_size_properties(name, n):
     halves.close()
 
 
+@pytest.mark.parametrize("name,n", [("config3", 100_000_000), ("config5", 125_000_000)])
+def test_full_shard_properties_on_the_device(name, n):
+    """BASELINE.json's own sizes (config 3: 100 M reads; config 5: one GPU's shard of 125 M): one outcome per read, the
+    table sums to the matched reads, two half shards add up to the whole shard entry by entry (what per-GPU shards + one
+    sum-reduce rely on), and a second run reproduces the table bit for bit.  Checked on the device: 89 M result rows are
+    not brought to the host."""
+    import torch
+    import ngs_barcode_count_amd as pkg
+    w = workloads.make(name)
+    entries = w.plan.table_entries
+    tabs = [torch.zeros(entries, dtype=torch.int32, device="cuda") for _ in range(3)]
+    torch.cuda.synchronize()
+    whole = _run(w, 0, n, eng=pkg.Engine(w.plan, device=0, table_ptr=tabs[0].data_ptr()), chunk=1 << 24)
+    c = whole.counters()
+    six = sum(c[k] for k in ("matched", "constant_region", "sample_barcode", "barcode", "duplicates", "low_quality"))
+    assert six == n == c["total_reads"] and c["unsupported_reads"] == 0 and c["duplicates"] == 0
+    assert int(tabs[0].sum(dtype=torch.int64)) == c["matched"]
+    assert 0.5 * n < c["matched"] < n
+    halves = _run(w, 0, n // 2, eng=pkg.Engine(w.plan, device=0, table_ptr=tabs[1].data_ptr()), chunk=1 << 24)
+    _run(w, n // 2, n - n // 2, eng=halves, chunk=1 << 24)
+    assert halves.counters() == c
+    assert torch.equal(tabs[0], tabs[1])
+    again = _run(w, 0, n, eng=pkg.Engine(w.plan, device=0, table_ptr=tabs[2].data_ptr()), chunk=(1 << 24) + 4096)
+    assert again.counters() == c and torch.equal(tabs[0], tabs[2])  # other batch boundaries, same table
+    for e in (whole, halves, again):
+        e.close()
+
+
 def test_specialised_kernel_takes_over_in_the_background(monkeypatch, tmp_path):
     """default mode, empty kernel cache: small batches start on the generic kernel; after 2^20 reads the
     specialised one is compiled on a worker thread and later submits switch to it -- same counts."""
