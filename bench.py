@@ -32,7 +32,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); a device copy reaches ~5-6.3 TB/s depending on the box
 # reads per step per GPU: the BASELINE.json sizes (config 4: 400 M over 8 GPUs; config 5: 1 B over 8 GPUs)
-DEFAULT_READS = {"config2": 10_000_000, "config3": 100_000_000, "config4": 50_000_000, "config5": 125_000_000}
+DEFAULT_READS = {"config2": 10_000_000, "config3": 100_000_000, "config4": 50_000_000, "config5": 125_000_000,
+                 "config5z": 125_000_000}
 WORKLOAD_TEXT = {
     "config2": "DEL [8]+3x{8} vs 4 samples + 3x1000 refs, clean reads, exact match only (BASELINE configs[1])",
     "config3": "DEL [8]+3x{8} vs 4 samples + 3x1000 refs, 1% substitutions + 0.1% N, 20% mismatch budgets, "
@@ -40,6 +41,7 @@ WORKLOAD_TEXT = {
     "config4": "DEL [8]+3x{8}+(12) random barcode vs 4 samples + 3x1000 refs, PCR duplicates (2 reads per molecule), "
                "1% substitutions + 0.1% N (BASELINE configs[3], per-GPU shard of 50M reads; set cleared every step)",
     "config5": "CRISPR {20} vs 100k guides, 1% substitutions + 0.1% N, <=4 mismatches (BASELINE configs[4], per-GPU shard of 125M reads)",
+    "config5z": "config5 with guide ranks drawn Zipf-like (P(k) ~ 1/k): the counter hot-spot variant of SURVEY.md 8(d)",
 }
 
 
@@ -204,7 +206,10 @@ def run_config(name, n, steps, warmup, world, rank, local, dev, legs):
     from ngs_barcode_count_amd import distributed as bcdist
     import workloads
 
-    w = workloads.make(name, n_molecules=(n * world) // 2 if name == "config4" else None)
+    if name == "config5z":
+        w = workloads.make("config5", zipf=True)
+    else:
+        w = workloads.make(name, n_molecules=(n * world) // 2 if name == "config4" else None)
     R = w.read_len
     with_qual = w.min_quality > 0
     # the counter table first: it is the randomly accessed one, so it should get the most contiguous device memory
@@ -412,7 +417,7 @@ def main():
         return
 
     host_sample = res.pop("_host_sample", None)
-    crispr = args.config == "config5"
+    crispr = args.config.startswith("config5")
     out = {
         "metric": "reads/sec (whole node), CRISPR 20nt vs 100k guides" if crispr else "reads/sec (whole node), 3x8nt DEL vs 3x1k refs",
         "value": res["value"],
@@ -455,7 +460,7 @@ def main():
     if legs and args.config == "config3":
         # the other BASELINE configs, each at its own size, a few steps each (the headline stays config 3)
         extra = []
-        for name in ("config2", "config4", "config5"):
+        for name in ("config2", "config4", "config5", "config5z"):
             r, _ = run_config(name, DEFAULT_READS[name], 3, 1, 1, 0, local, dev, False)
             extra.append({k: r[k] for k in ("config", "workload", "reads_per_step_per_gpu", "value", "ms_per_step", "roofline",
                                             "outcomes")})

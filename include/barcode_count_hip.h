@@ -263,6 +263,9 @@ typedef struct bc_synth_params {
   uint8_t lowq_lo, lowq_hi;     /* low-quality Phred range, inclusive */
   uint64_t n_molecules;  /* 0: every read is its own molecule; else reads are draws from this many
                             molecules (PCR duplicates) */
+  uint32_t zipf;         /* 1: counted-barcode indices follow a Zipf-like law with exponent 1 (P(rank k) ~ 1/k; the
+                            hot-spot variant of SURVEY.md 8(d)) instead of the uniform one */
+  uint32_t reserved;
 } bc_synth_params;
 
 bc_synth *bc_synth_create(const bc_plan *p, const bc_synth_params *params);

@@ -138,6 +138,7 @@ struct DevPlan {
   uint32_t n_runs;
   uint32_t discard_counts;  // sample file given but no sample group: add_count hits a temporary (info.rs:762-766)
   uint32_t has_fmtn;
+  uint32_t no_repair;   // the scheme has lower-case constants: fix_constant_region can only fail (bc_plan.cpp)
   // random barcode (PCR-duplicate collapse, info.rs:770-802): the capture is kept raw; its base-5
   // code (A,C,T,G,N -> 0,1,2,3,4) and the dense tuple index form one 64-bit key of a device hash set
   uint32_t has_random, rnd_off, rnd_len;

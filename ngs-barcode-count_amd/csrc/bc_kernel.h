@@ -184,6 +184,71 @@ __device__ __forceinline__ void wave_seeded_min(const DevGroup& G, uint32_t q1, 
   idx_out = (uint32_t)__shfl((int)s.idx, first);
 }
 
+// The coarse index for up to FOUR N-free captures at once, sixteen lanes each (lanes 16 s .. 16 s + 15 serve capture s):
+// a wavefront has one to three captures waiting for this search far more often than none or many, and one after the
+// other each of them costs two memory round trips with three quarters of the lanes idle.  (q1, q2) = the capture of the
+// calling lane's segment; seg_on = that segment has one.  Per segment: the smallest key (distance + 1, 0 for the
+// capture itself), whether exactly one reference has it, that reference -- valid when kmin <= nb (decided, as in
+// wave_scan_blocks_wide); otherwise the full index has to be walked for that capture.
+__device__ __forceinline__ void coarse_probe_x4(const DevGroup& G, uint32_t q1, uint32_t q2, bool seg_on, uint32_t& kmin_out,
+                                                bool& unique_out, uint32_t& idx_out) {
+  constexpr int kMaxBlocks = 3;
+  const uint32_t nb = G.seed2_nb, blen = G.seed2_blen, n_idx = G.n_idx;
+  const uint32_t bm = (1u << blen) - 1u;
+  const uint32_t nbk = 1u << (2 * blen);
+  const uint32_t lane = __lane_id(), j = lane & 15u;
+  const BC_GLOBAL uint4* entries = reinterpret_cast<const BC_GLOBAL uint4*>(G.seed2_list());
+  Nearest s;
+  nearest_init(s);
+  uint32_t beg[kMaxBlocks], end[kMaxBlocks];
+#pragma unroll
+  for (int b = 0; b < kMaxBlocks; ++b) {
+    beg[b] = end[b] = 0;
+    if ((uint32_t)b < nb && seg_on) {
+      const uint32_t val = ((q1 >> (b * blen)) & bm) | (((q2 >> (b * blen)) & bm) << blen);
+      const BC_GLOBAL uint32_t* off = G.seed2_off() + (size_t)b * (nbk + 1);
+      beg[b] = off[val];
+      end[b] = off[val + 1];
+    }
+  }
+  auto score = [&](const uint4& x, uint32_t b, bool on) {
+    const uint32_t diff = (q1 ^ x.x) | (q2 ^ x.y);
+    bool earlier = false;  // equal to the capture on an earlier block: scored there
+    for (uint32_t p = 0; p < b; ++p) earlier = earlier || ((diff >> (p * blen)) & bm) == 0u;
+    if (on && !earlier) nearest_add(s, popc(diff), x.z, diff == 0u);
+  };
+  uint4 e[kMaxBlocks];
+#pragma unroll
+  for (int b = 0; b < kMaxBlocks; ++b) {  // the first sixteen entries of every bucket: one round trip
+    const uint32_t i = beg[b] + j;
+    e[b] = make_uint4(0, 0, 0, 0);
+    if (i < end[b]) e[b] = entries[(size_t)b * n_idx + i];
+  }
+#pragma unroll
+  for (int b = 0; b < kMaxBlocks; ++b) {
+    score(e[b], (uint32_t)b, beg[b] + j < end[b]);
+    for (uint32_t i = beg[b] + 16u + j; __any(i - j < end[b]); i += 16u) {  // longer buckets (wave-uniform trip count)
+      const bool on = i < end[b];
+      uint4 x = make_uint4(0, 0, 0, 0);
+      if (on) x = entries[(size_t)b * n_idx + i];
+      score(x, (uint32_t)b, on);
+    }
+  }
+  uint32_t kmin = s.key;
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {  // minimum over the segment's sixteen lanes
+    const uint32_t t = (uint32_t)__shfl_xor((int)kmin, o);
+    kmin = t < kmin ? t : kmin;
+  }
+  const unsigned long long holders = __ballot(s.key == kmin);
+  const uint32_t seg_mask = (uint32_t)(holders >> (lane & 48u)) & 0xFFFFu;  // never empty: the minimum has a holder
+  const int first = (int)(lane & 48u) + (__ffs(seg_mask) - 1);
+  const uint32_t cnt = (uint32_t)__shfl((int)s.count, first);
+  idx_out = (uint32_t)__shfl((int)s.idx, first);
+  unique_out = __popc(seg_mask) == 1 && cnt == 1u && kmin != 0xFFFFFFFFu;
+  kmin_out = kmin;
+}
+
 // A capture with up to two 'N's against plain references: 'N' is free (parse.rs:569), so its
 // distance to a reference is that of the capture with each N replaced by the reference's base
 // there.  The nearest references of the capture are therefore those of its 4 (16) substitutions
@@ -265,6 +330,18 @@ __device__ __forceinline__ void table_add(uint32_t* p) {
   atomicAdd(p, 1u);
 #endif
 }
+
+// ---- hot-counter cache -------------------------------------------------------------------------------------
+// A library with a few very abundant members (a CRISPR screen's top guides, an enriched compound) sends a large share
+// of the matched reads to a handful of counters, and memory-side atomics on ONE address run one after the other
+// (~60 M/s: a Zipf-like guide distribution ran 13 x slower than a uniform one).  Every workgroup therefore keeps
+// kHotSlots counters in LDS, claimed first come first served by the table indices it meets (tag = index, never
+// evicted): an abundant index is all but certain to claim its slot within the workgroup's first few hundred reads, and
+// from then on costs an LDS add; everything else goes to the table as before.  The slot of an index is a hash seeded
+// by the workgroup, so two abundant indices that collide in one workgroup do not in the others.  The cached counts are
+// added to the table once, when the workgroup ends.  Plans whose table index fits 32 bits.
+constexpr uint32_t kHotBits = 8, kHotSlots = 1u << kHotBits, kHotEmpty = 0xFFFFFFFFu;
+constexpr uint32_t kHotBytes = kHotSlots * 8u;
 
 // ---- device hash set of 64-bit keys (the AHashSet<String> per tuple of info.rs:663, flattened) ----
 constexpr unsigned long long kEmptyKey = ~0ull;
@@ -412,6 +489,43 @@ struct DeviceOps {
                                               bool need) const {
     uint32_t out = kFail;
     unsigned long long todo = __ballot(need);
+    if (G.seed_nb && G.seed2_nb && G.seed2_nb <= 3u && G.n_odd == 0u) {
+      // plain captures (no 'N', no foreign byte) four at a time through the coarse index; what it cannot decide (the
+      // nearest reference is three or more mismatches away, or there is none) stays in `todo` for the full search
+      unsigned long long plain = __ballot(need && qn == 0u && qx == 0u);
+      while (plain) {
+        int src[4];
+        int n_seg = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          src[k] = plain ? __ffsll(plain) - 1 : src[0];
+          if (plain) {
+            plain &= plain - 1;
+            ++n_seg;
+          }
+        }
+        const uint32_t seg = lane >> 4;
+        const int my_src = seg == 0u ? src[0] : (seg == 1u ? src[1] : (seg == 2u ? src[2] : src[3]));
+        const bool seg_on = (int)seg < n_seg;
+        const uint32_t b1 = (uint32_t)__shfl((int)q1, my_src);
+        const uint32_t b2 = (uint32_t)__shfl((int)q2, my_src);
+        uint32_t kmin, idx;
+        bool uniq;
+        coarse_probe_x4(G, b1, b2, seg_on, kmin, uniq, idx);
+        const bool decided = seg_on && kmin != 0xFFFFFFFFu && kmin <= G.seed2_nb;
+        const uint32_t res = (uniq && (kmin == 0u || kmin - 1u <= G.max_err)) ? idx : kFail;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (k >= n_seg) break;
+          const bool d_k = __shfl((int)decided, 16 * k) != 0;
+          const uint32_t r_k = (uint32_t)__shfl((int)res, 16 * k);
+          if (d_k) {
+            if ((int)lane == src[k]) out = r_k;
+            todo &= ~(1ull << src[k]);
+          }
+        }
+      }
+    }
     while (todo) {
       const int src = __ffsll(todo) - 1;
       todo &= todo - 1;
@@ -470,8 +584,19 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
     ops.area = area;
     ops.with_tables = lhash_vec != 0u;
   }
+  // flags bit 2: the workgroup's hot-counter cache sits between the tables and the tiles
+  const bool hot = (flags & 4u) != 0u;
+  const uint32_t hot_seed = blockIdx.x * 0x85EBCA6Bu;
+  uint32_t* hot_tag = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(smem) + lhash_vec * 16u);
+  uint32_t* hot_cnt = hot_tag + kHotSlots;
+  if (hot) {
+    for (uint32_t i = tid; i < kHotSlots; i += kTPB) {
+      hot_tag[i] = kHotEmpty;
+      hot_cnt[i] = 0u;
+    }
+  }
   const uint32_t two = (with_qual && pipe) ? 2u : 1u;
-  ops.tile = reinterpret_cast<uint8_t*>(smem) + lhash_vec * 16u + wave * region * two;
+  ops.tile = reinterpret_cast<uint8_t*>(smem) + lhash_vec * 16u + (hot ? kHotBytes : 0u) + wave * region * two;
   ops.qtile = ops.tile + (two == 2u ? region : 0u);
   ops.region = region;
   ops.lane = lane;
@@ -577,7 +702,21 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
     // fetches above are older: nothing in the next tile has to wait for the atomic to retire.
     ops.pending_add = 0;
     if (!pl.has_random) {
-      const bool add = active && outcome == kMatched && !pl.discard_counts && !(pl.abl() & 0x4u);
+      bool add = active && outcome == kMatched && !pl.discard_counts && !(pl.abl() & 0x4u);
+      if (hot && !pl.sparse && __any(add)) {
+        // the workgroup's LDS counters first: an index that owns (or can still claim) its slot is counted there
+        const uint32_t key = (uint32_t)r.dense_idx;
+        const uint32_t h = ((key ^ hot_seed) * 0x9E3779B1u) >> (32u - kHotBits);
+        uint32_t tag = add ? hot_tag[h] : key ^ 1u;
+        if (add && tag == kHotEmpty) {
+          const uint32_t old = atomicCAS(&hot_tag[h], kHotEmpty, key);
+          tag = old == kHotEmpty ? key : old;
+        }
+        if (add && tag == key) {
+          atomicAdd(&hot_cnt[h], 1u);
+          add = false;
+        }
+      }
       if (__any(add)) {
         if (add) {
           if (pl.sparse)
@@ -604,6 +743,12 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
   if (tid < kNCounters) {
     const uint32_t v = s_cnt[tid];
     if (v) atomicAdd(&counters[tid], (unsigned long long)v);
+  }
+  if (hot) {  // the cached counts, one table add per used slot
+    for (uint32_t i = tid; i < kHotSlots; i += kTPB) {
+      const uint32_t c = hot_cnt[i];
+      if (c) atomicAdd(&table[hot_tag[i]], c);
+    }
   }
 }
 

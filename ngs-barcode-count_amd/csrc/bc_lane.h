@@ -627,7 +627,7 @@ BC_HD bool locate(const DevPlan& pl, Ops& ops, const Planes<NW>& P, const uint32
       if ((o >> 5) == (uint32_t)w) z[w] &= ~(1u << (o & 31u));
   }
 
-  if (!(pl.abl() & 0x1u) && ops.any(live && !found)) {
+  if (!pl.no_repair && !(pl.abl() & 0x1u) && ops.any(live && !found)) {
     uint32_t cand[NWW];
     low_bits<NWW>(cand, len > L ? len - L : 0u);
 #pragma unroll

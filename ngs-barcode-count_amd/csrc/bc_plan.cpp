@@ -147,6 +147,10 @@ bool bc_plan::lower(HostDevPlan& out) const {
     set_error("unsupported scheme: format length must be 1.." + std::to_string(kMaxNW * 32));
     return false;
   }
+  if (literal_n_constant) {
+    set_error("unsupported scheme: lower-case 'n' constants (literal 'N' bases) need the wave-per-read kernel");
+    return false;
+  }
   if (max_constant > 31) {
     set_error("unsupported plan: --max-errors-constant above 31");
     return false;
@@ -156,6 +160,7 @@ bool bc_plan::lower(HostDevPlan& out) const {
   P.L = length;
   P.RL = (uint32_t)regions_string.size();
   P.max_const = max_constant;
+  P.no_repair = lowercase_constants ? 1u : 0u;
   uint32_t nb = 0;
   while ((1u << nb) <= (uint32_t)max_constant) ++nb;  // counters hold 0 .. 2^nb-1 >= max_constant
   P.nb = nb;
@@ -522,6 +527,134 @@ bool bc_plan::lower(HostDevPlan& out) const {
   return true;
 }
 
+// The plan of the wave-per-read kernel (bc_long.h): the same group order, key digits and strides as lower(), none of
+// its width limits.
+bool bc_plan::lower_long(LongHost& out) const {
+  if (!unsupported.empty()) {
+    set_error("unsupported scheme: " + unsupported);
+    return false;
+  }
+  if (length == 0 || length > 65535u) {
+    set_error("unsupported scheme: format length must be 1..65535");
+    return false;
+  }
+  LongPlan& P = out.plan;
+  memset(&P, 0, sizeof(P));
+  P.L = length;
+  P.RL = (uint32_t)regions_string.size();
+  P.max_const = max_constant;
+  P.no_repair = lowercase_constants ? 1u : 0u;
+  P.quality_on = min_quality > 0.0f ? 1u : 0u;
+  for (uint32_t p = 0; p < pos.size(); ++p) {
+    if (pos[p].kind == kPosConst) {
+      out.const_pos.push_back(p);
+      out.const_chr.push_back((uint8_t)pos[p].letter);
+    } else if (pos[p].kind == kPosFmtN) {
+      out.fmtn_pos.push_back(p);
+    }
+  }
+  P.n_const = (uint32_t)out.const_pos.size();
+  P.n_fmtn = (uint32_t)out.fmtn_pos.size();
+  {
+    uint32_t n = 0;
+    size_t i = 0;
+    const std::string& r = regions_string;
+    while (i < r.size()) {
+      size_t j = i;
+      while (j < r.size() && r[j] == r[i]) ++j;
+      if (r[i] != 'C' && j < r.size()) {
+        if (n >= (uint32_t)kMaxRuns) {
+          set_error("unsupported scheme: more than " + std::to_string(kMaxRuns) + " barcode runs");
+          return false;
+        }
+        P.run_off[n] = (uint32_t)i;
+        P.run_len[n] = (uint32_t)(j - i);
+        P.run_thr[n] = quality_threshold((uint32_t)(j - i));
+        ++n;
+      }
+      i = j;
+    }
+    P.n_runs = n;
+  }
+  struct Pending {
+    const FormatGroup* g;
+    const KnownSet* set;
+    uint32_t max_err;
+  };
+  std::vector<Pending> order;
+  for (const auto& g : groups)
+    if (g.type == kGroupSample) order.push_back({&g, &samples, max_sample});
+  for (uint32_t b = 1; b <= barcode_num; ++b)
+    for (const auto& g : groups)
+      if (g.type == kGroupBarcode && g.number == b) order.push_back({&g, &counted[b - 1], max_barcode[b - 1]});
+  if (order.size() > (size_t)kMaxGroups) {
+    set_error("unsupported scheme: too many barcode groups");
+    return false;
+  }
+  P.n_groups = (uint32_t)order.size();
+  out.ref_text.assign(order.size(), {});
+  out.ref_off.assign(order.size(), {});
+  out.n_samples = sample_barcode ? (uint32_t)samples.size() : 1u;
+  P.discard_counts = (!sample_barcode && samples.size() > 0 && !random_barcode) ? 1u : 0u;
+  unsigned __int128 entries = 1;
+  for (int i = (int)order.size() - 1; i >= 0; --i) {
+    const Pending& pd = order[i];
+    LongGroup& G = P.groups[i];
+    G.type = pd.g->type;
+    G.off = pd.g->off;
+    G.len = pd.g->len;
+    G.n_refs = (uint32_t)pd.set->size();
+    G.max_err = pd.max_err;
+    G.table_stride = (uint64_t)entries;
+    if (G.n_refs == 0) {
+      if (G.len > 27) {
+        set_error("unsupported plan: barcodes without a conversion file must be at most 27 bases");
+        return false;
+      }
+      P.sparse = 1;
+      for (uint32_t k = 0; k < G.len; ++k) entries *= 5;
+    } else {
+      entries *= G.n_refs;
+      auto& off = out.ref_off[i];
+      auto& text = out.ref_text[i];
+      for (const std::string& s : pd.set->seqs) {
+        off.push_back((uint32_t)text.size());
+        text.insert(text.end(), s.begin(), s.end());
+      }
+      off.push_back((uint32_t)text.size());
+    }
+    if (entries >= ((unsigned __int128)1 << 63)) {
+      set_error("unsupported plan: the (sample, barcode tuple) space does not fit a 64-bit key");
+      return false;
+    }
+  }
+  if (!P.sparse && entries > ((unsigned __int128)1 << 40)) {
+    set_error("unsupported plan: dense counter table above 2^40 entries");
+    return false;
+  }
+  out.table_entries = (uint64_t)entries;
+  if (random_barcode) {
+    for (const auto& g : groups) {
+      if (g.type != kGroupRandom) continue;
+      if (g.len == 0 || g.len > 27) {
+        set_error("unsupported scheme: random barcodes must be 1..27 bases");
+        return false;
+      }
+      unsigned __int128 space = 1;
+      for (uint32_t i = 0; i < g.len; ++i) space *= 5;
+      if (space * entries >= ((unsigned __int128)1 << 64) - 1) {
+        set_error("unsupported plan: (barcode tuple, random barcode) does not fit a 64-bit key");
+        return false;
+      }
+      P.has_random = 1;
+      P.rnd_off = g.off;
+      P.rnd_len = g.len;
+      P.rspace = (uint64_t)space;
+    }
+  }
+  return true;
+}
+
 // ------------------------------------------------------------------------------------------------
 // C ABI: plan
 // ------------------------------------------------------------------------------------------------
@@ -607,7 +740,13 @@ bc_plan* bc_plan_create(const char* text, size_t len) {
         p->regex_string.push_back(u);
         p->regions_string.push_back('C');
         p->pos.push_back({kPosConst, u, -1});
-        if (c != u) p->unsupported = "lower-case letters in the sequence format";
+        // A lower-case constant: the regex has the upper-case letter (info.rs:298), format_string keeps the lower-case
+        // one (info.rs:299).  Anchoring is unaffected; a repair can never succeed, because the repaired read carries
+        // the lower-case letter (parse.rs:270-283), which the regex then does not match (parse.rs:92-95).
+        if (c != u) p->lowercase_constants = true;
+        // (a run of lower-case n's lands here too -- the token pattern is case-insensitive, contains('N') is not:
+        // the regex then wants literal 'N' bases.  Only the wave-per-read kernel compares letters as they are.)
+        if (u == 'N') p->literal_n_constant = true;
       }
       p->format_string += tok;
       p->constant_region_length += (uint32_t)tok.size();
@@ -753,14 +892,18 @@ uint32_t bc_plan_quality_threshold(const bc_plan* p, uint32_t run_len) { return 
 
 uint64_t bc_plan_table_entries(const bc_plan* p) {
   bc::HostDevPlan h;
-  if (!p->lower(h)) return 0;
-  return h.plan.sparse ? 0 : h.table_entries;
+  if (p->lower(h)) return h.plan.sparse ? 0 : h.table_entries;
+  bc::LongHost lh;  // plans only the wave-per-read kernel runs (bc_long.h)
+  if (!p->lower_long(lh)) return 0;
+  return lh.plan.sparse ? 0 : lh.table_entries;
 }
 
 int bc_plan_mode(const bc_plan* p) {
   bc::HostDevPlan h;
-  if (!p->lower(h)) return 0;
-  return h.plan.sparse ? 2 : 1;
+  if (p->lower(h)) return h.plan.sparse ? 2 : 1;
+  bc::LongHost lh;
+  if (!p->lower_long(lh)) return 0;
+  return lh.plan.sparse ? 2 : 1;
 }
 
 }  // extern "C"

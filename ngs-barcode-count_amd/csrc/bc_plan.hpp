@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "bc_device_plan.h"
+#include "bc_long.h"
 
 namespace bc {
 
@@ -63,6 +64,17 @@ struct HostDevPlan {
   uint32_t n_samples = 1;
 };
 
+// host form of the wave-per-read kernel's plan (bc_long.h): device pointers still null
+struct LongHost {
+  LongPlan plan;
+  std::vector<uint32_t> const_pos, fmtn_pos;
+  std::vector<uint8_t> const_chr;
+  std::vector<std::vector<uint8_t>> ref_text;   // per plan.groups entry
+  std::vector<std::vector<uint32_t>> ref_off;
+  uint64_t table_entries = 0;
+  uint32_t n_samples = 1;
+};
+
 }  // namespace bc
 
 struct bc_plan {
@@ -77,6 +89,8 @@ struct bc_plan {
   std::vector<bc::FormatPos> pos;       // one per byte a match spans
   std::vector<bc::FormatGroup> groups;  // in order of appearance
   std::string unsupported;              // non-empty: why the engine cannot run this scheme
+  bool lowercase_constants = false;     // some constant is lower-case in the scheme: no repair can succeed (bc_plan.cpp)
+  bool literal_n_constant = false;      // ... and some of them are n's: the regex wants literal 'N' bases
 
   // BarcodeConversions (info.rs:338-343)
   bc::KnownSet samples;
@@ -92,5 +106,7 @@ struct bc_plan {
   void recompute_budgets();
   // lowers to the device form; false + set_error() when the engine cannot run the plan
   bool lower(bc::HostDevPlan& out) const;
+  // the same for the wave-per-read kernel: any read length, group length, reference length and constant budget
+  bool lower_long(bc::LongHost& out) const;
   uint32_t quality_threshold(uint32_t run_len) const;
 };

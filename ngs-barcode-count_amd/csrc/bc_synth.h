@@ -16,6 +16,8 @@ struct SynthGroup {
   uint32_t type;  // GroupType
   uint32_t off, len;
   uint32_t n_refs;     // 0: random bases
+  uint32_t zmul;       // Zipf variant: rank k is reference (k - 1) * zmul mod n_refs (coprime: the abundant references
+                       // are scattered over the set, as they are in a real library, not its first few entries)
   const char* refs;    // n_refs * len ASCII bases
 };
 
@@ -26,6 +28,7 @@ struct SynthDev {
   uint32_t p_sub, p_n, p_lowq;  // probabilities * 2^32
   uint32_t phred_lo, phred_hi, lowq_lo, lowq_hi;
   uint64_t n_molecules;
+  uint32_t zipf;                 // counted-barcode indices drawn octave-uniformly (P(k) ~ 1/k) instead of uniformly
   uint32_t n_groups;
   uint32_t n_sb;                 // groups that can receive low qualities (sample + counted)
   SynthGroup groups[kMaxGroups];
@@ -74,7 +77,18 @@ BC_HD void synth_begin(const SynthDev& S, uint64_t i, SynthRead& R) {
   }
   for (uint32_t g = 0; g < S.n_groups; ++g) {
     const uint64_t hg = synth_mix(S.seed ^ 0xB0C0DEull, R.mol, 16 + g);
-    R.ref_idx[g] = S.groups[g].n_refs ? (uint32_t)(hg % S.groups[g].n_refs) : 0u;
+    const uint32_t nr = S.groups[g].n_refs;
+    R.ref_idx[g] = nr ? (uint32_t)(hg % nr) : 0u;
+    if (S.zipf && nr > 1u && S.groups[g].type == kGroupBarcode) {
+      // Zipf-like with exponent 1, in integer arithmetic (the same on host and device): the octave [2^b, 2^(b+1)) of
+      // the rank k is uniform, k is uniform inside it, so P(k) = 1 / (B 2^b) ~ 1/k.  Rank 1 is reference 0.
+      uint32_t octaves = 0;
+      while ((1ull << octaves) <= nr) ++octaves;  // ranks 1 .. nr span `octaves` octaves
+      const uint32_t b = (uint32_t)((hg >> 40) % octaves);
+      uint64_t k = (1ull << b) + ((hg & 0xFFFFFFFFull) % (1ull << b));
+      if (k > nr) k = (k % nr) + 1ull;
+      R.ref_idx[g] = (uint32_t)(((k - 1ull) * S.groups[g].zmul) % nr);
+    }
     R.rnd_bits[g] = hg;
   }
 }

@@ -360,8 +360,8 @@ def test_submit_host_equals_submit_device():
 
 def test_errors_are_loud():
     pkg = _pkg()
-    with pytest.raises(pkg.BarcodeCountError):  # lower-case scheme letters: refused, never guessed
-        pkg.Engine(pkg.Plan("[8]acgt{8}"), device=0)
+    with pytest.raises(pkg.BarcodeCountError):  # a token mixing 'N' and 'n': the reference's regex and format_string differ in length
+        pkg.Engine(pkg.Plan("[8]ACGTNnN{8}"), device=0)
     with pytest.raises(pkg.BarcodeCountError):  # raw barcodes that do not fit a 64-bit key
         pkg.Engine(pkg.Plan("[20]ACGT{20}TT{20}"), device=0)
     p = make_plan(dict(scheme="ACGTACGT{8}TTGG", counted=[["ACGTACGT"]], kwargs=dict(min_quality=10.0)))
@@ -455,4 +455,99 @@ def test_exhaustive_small_domain(kernel):
         check(seq, qual, ln)
     assert total == sum(8 ** k for k in range(9)) + 8 * 4 ** 9
     check_kernel(eng, kernel)
+    eng.close()
+
+
+@pytest.mark.parametrize("kernel", ["generic", "specialised"], indirect=True)
+@pytest.mark.parametrize("scheme,long_only", [("[8]AGCTacgaATCG{8}TGGA{8}tgga{8}ACTAGAT", False),
+                                              ("[8]AGCTACGAATCG{8}TGnnGA{8}TGGA{8}ACTAGAT", True)])
+def test_lower_case_scheme_letters(kernel, scheme, long_only):
+    """lower-case constants anchor like upper-case ones and make every repair fail (info.rs:298-299, parse.rs:270-283);
+    lower-case n's are LITERAL 'N' bases to the regex (the token pattern is case-insensitive, contains('N') is not):
+    those schemes run on the wave-per-read kernel"""
+    c = cases.build_case("del_mismatch_quality", seed=72, n=10)
+    rng = np.random.default_rng(72)
+    gen_scheme = scheme.upper().replace("NN", "AC") if long_only else scheme.upper()
+    c["reads"] = readgen.gen_reads(rng, gen_scheme, 1500, 100, list(c["samples"]), c["counted"], p_sub=0.01, p_n=0.004)
+    if long_only:  # put the literal N's the regex wants into two thirds of the reads
+        at = scheme.index("nn") - 3 + 8 - len("[8]") + 3  # offset of the n's inside a match: "[8]" stands for 8 bases
+        lay_off = 8 + len("AGCTACGAATCG") + 8 + 2
+        reads = []
+        for i, (s, q) in enumerate(c["reads"]):
+            k = s.find("TGACGA")
+            if i % 3 and k >= 0:
+                s = s[:k + 2] + "NN" + s[k + 4:]
+            reads.append((s, q))
+        c["reads"] = reads
+    c["scheme"] = scheme
+    plan = make_plan(c)
+    seq, qual, lens = readgen.to_arrays(c["reads"])
+    eng, outc, idx = run_device(plan, seq, qual, lens, seq.shape[1], seq.shape[1])
+    o = parity.check_per_read(c, plan, outc, idx, False)
+    got = eng.counters()
+    assert {k: got[k] for k in o.counters} == o.counters and eng.result_rows() == o.rows()
+    assert o.counters["matched"] > 100 and o.counters["constant_region"] > 0
+    if long_only:
+        assert eng.kernel_name() == "long_match_kernel"
+    else:
+        check_kernel(eng, kernel)
+    eng.close()
+
+
+LONG_SCHEME = "[8]ACGTTGCA{40}GGATCC{36}TTGACA"
+
+
+def _long_cases():
+    """inputs beyond the lane-per-read kernel's widths (refused in round 1): reads above 320 bases, barcode
+    groups and known barcodes above 32 bases, more than 31 tolerated constant-region errors"""
+    out = {}
+    rng = np.random.default_rng(91)
+    c = cases.build_case("del_mismatch_quality", seed=61, n=10)
+    c["reads"] = readgen.gen_reads(rng, c["scheme"], 900, 520, list(c["samples"]), c["counted"], p_sub=0.02, p_n=0.004)
+    out["reads_of_520_bases"] = c
+    c = cases.build_case("del_random", seed=62, n=10)
+    c["reads"] = readgen.gen_reads(rng, c["scheme"], 900, 400, list(c["samples"]), c["counted"], p_sub=0.01, p_n=0.004,
+                                   dup_frac=0.3)
+    out["random_barcode_reads_of_400_bases"] = c
+    c = cases.build_case("raw_counted", seed=63, n=10)
+    pool = [readgen.make_set(rng, 12, 9, 2), readgen.make_set(rng, 5, 4, 2)]
+    c["reads"] = readgen.gen_reads(rng, c["scheme"], 700, 350, None, pool, p_sub=0.02, p_n=0.01)
+    out["raw_keys_reads_of_350_bases"] = c
+    s = readgen.make_set(rng, 4, 8, 3)
+    c = {"scheme": LONG_SCHEME, "samples": {x: "S%d" % i for i, x in enumerate(s)},
+         "counted": [readgen.make_set(rng, 30, 40, 6) + ["ACGT" * 9], readgen.make_set(rng, 20, 36, 6)],
+         "kwargs": dict(min_quality=18.0)}
+    # (the 36-base entry of the 40-base group is a reference of another length: compared on the common prefix)
+    c["reads"] = readgen.gen_reads(rng, LONG_SCHEME, 900, 150, s, [c["counted"][0][:-1], c["counted"][1]], p_sub=0.03,
+                                   p_n=0.006)
+    out["groups_of_40_and_36_bases"] = c
+    c = cases.build_case("del_mismatch_quality", seed=64, n=900)
+    c["kwargs"] = dict(c.get("kwargs", {}), max_constant=40)
+    out["forty_constant_errors_allowed"] = c
+    return out
+
+
+@pytest.mark.parametrize("name", ["reads_of_520_bases", "random_barcode_reads_of_400_bases", "raw_keys_reads_of_350_bases",
+                                  "groups_of_40_and_36_bases", "forty_constant_errors_allowed"])
+@pytest.mark.parametrize("use_lens", [False, True])
+def test_wave_per_read_kernel(name, use_lens):
+    c = _long_cases()[name]
+    if not use_lens:
+        rl = min(len(s) for s, _ in c["reads"])
+        c["reads"] = [(s[:rl], q[:rl]) for s, q in c["reads"]]
+    plan = make_plan(c)
+    seq, qual, lens = readgen.to_arrays(c["reads"])
+    stride = seq.shape[1]
+    eng, outc, idx = run_device(plan, seq, qual, lens if use_lens else None, stride, stride)
+    assert eng.kernel_name() == "long_match_kernel"
+    o = parity.oracle_for(c)
+    exp = [o.process(s, q) for s, q in c["reads"]]
+    if not plan.random_barcode:  # (which copy of a PCR duplicate counts as the duplicate depends on the order of arrival)
+        bad = [i for i, e in enumerate(exp) if int(outc[i]) != parity.CODE[e]]
+        assert not bad, (bad[:3], exp[bad[0]], int(outc[bad[0]]), c["reads"][bad[0]])
+    got = eng.counters()
+    assert {k: got[k] for k in o.counters} == o.counters, (got, o.counters)
+    assert got["total_reads"] == len(c["reads"]) and got["unsupported_reads"] == 0
+    assert eng.result_rows() == o.rows()
+    assert o.counters["matched"] > 0
     eng.close()

@@ -193,3 +193,22 @@ def test_quality_line_of_another_length_than_the_sequence_line():
     outc, idx, entries, discard = emu_lib.emulate(plan, seq.reshape(-1), qual.reshape(-1), lens, st, st, qlens=qlens)
     o = parity.check_per_read(c, plan, outc, idx, discard)
     assert o.counters["low_quality"] > 0 and o.counters["matched"] > 0
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_lower_case_constants_anchor_but_never_repair(variant):
+    """info.rs:298-299: the regex gets the upper-cased constants, format_string keeps them as written, so a repaired
+    read carries lower-case letters the regex cannot match: anchored reads count as usual, reads that would need a
+    repair are constant-region errors"""
+    c = cases.build_case("del_mismatch_quality", seed=71, n=800)
+    upper = parity.oracle_for(c)
+    for s, q in c["reads"]:
+        upper.process(s, q)
+    c["scheme"] = "[8]AGCTacgaATCG{8}TGGA{8}tgga{8}ACTAGAT"
+    plan = emu_lib.make_plan(c, variant)
+    assert plan.format_string == "NNNNNNNNAGCTacgaATCGNNNNNNNNTGGANNNNNNNNtggaNNNNNNNNACTAGAT"
+    seq, qual, lens = readgen.to_arrays(c["reads"])
+    stride = seq.shape[1]
+    outc, idx, entries, discard = emu_lib.emulate(plan, seq.reshape(-1), qual.reshape(-1), lens, stride, stride)
+    o = parity.check_per_read(c, plan, outc, idx, discard)
+    assert o.counters["constant_region"] > upper.counters["constant_region"] and o.counters["matched"] > 0

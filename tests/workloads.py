@@ -12,7 +12,7 @@ class Workload:
     pass
 
 
-def make(name, n_sets=None, lib=None, n_molecules=None, read_len=100):
+def make(name, n_sets=None, lib=None, n_molecules=None, read_len=100, zipf=False):
     """name: config2 | config3 | config5.  n_sets = (samples, refs per counted barcode...) overrides the
     BASELINE sizes (tests use smaller sets so the CPU oracle stays fast)."""
     w = Workload()
@@ -64,7 +64,8 @@ def make(name, n_sets=None, lib=None, n_molecules=None, read_len=100):
         for i, s in enumerate(w.counted[0]):
             plan.add_counted(0, s, "guide_%d" % i)
         w.kwargs = {}
-        w.synth_args = dict(seed=5, p_sub=0.01, p_n=0.001)
+        # zipf: the hot-spot variant of SURVEY.md 8(d) -- guide ranks drawn with P(k) ~ 1/k instead of uniformly
+        w.synth_args = dict(seed=5, p_sub=0.01, p_n=0.001, zipf=zipf)
         w.min_quality = 0.0
     else:
         raise KeyError(name)
