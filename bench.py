@@ -212,24 +212,36 @@ def run_config(name, n, steps, warmup, world, rank, local, dev, legs):
         w = workloads.make(name, n_molecules=(n * world) // 2 if name == "config4" else None)
     R = w.read_len
     with_qual = w.min_quality > 0
-    # the counter table first: it is the randomly accessed one, so it should get the most contiguous device memory
-    # (largest page fragments) the process can have
-    table = torch.zeros(w.plan.table_entries, dtype=torch.int32, device=dev)
+    # N > 1: the counter table is this process's own tensor, so that it can be reduced with RCCL (allocated first: it is
+    # the randomly accessed one and should get the most contiguous device memory the process can have).  N = 1: the
+    # engine owns it, as in the command-line program.
+    table = torch.zeros(w.plan.table_entries, dtype=torch.int32, device=dev) if world > 1 else None
     torch.cuda.synchronize()
-    # --- resident inputs: this rank's contiguous shard of the seeded read stream -------------------
-    dseq = torch.empty(n * R, dtype=torch.uint8, device=dev)
-    dqual = torch.empty(n * R, dtype=torch.uint8, device=dev)
-    first_read, _ = bcdist.shard(n * world, rank, world)
-    w.synth.generate_device(local, None, first_read, n, dseq.data_ptr(), dqual.data_ptr())
+    # --- resident inputs: this rank's contiguous shard of the seeded read stream, one batch per step -----------------
+    # Every step counts reads it has not seen before (a job never counts the same batch twice), as many distinct
+    # batches as the HBM holds next to the table; with more steps than that the batches are gone through again.
+    batch_bytes = n * R * (2 if with_qual else 1)
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    n_batches = int(max(1, min(steps, (free_b - (12 << 30)) // batch_bytes)))
+    first_read, _ = bcdist.shard(n * n_batches * world, rank, world)
+    batches = []
+    for k in range(n_batches):
+        bs = torch.empty(n * R, dtype=torch.uint8, device=dev)
+        bq = torch.empty(n * R, dtype=torch.uint8, device=dev) if with_qual else None
+        w.synth.generate_device(local, None, first_read + k * n, n, bs.data_ptr(), bq.data_ptr() if with_qual else None)
+        batches.append((bs, bq))
     torch.cuda.synchronize()
-    eng = pkg.Engine(w.plan, device=local, table_ptr=table.data_ptr())
-    qptr = dqual.data_ptr() if with_qual else None
+    dseq, dqual = batches[0]
+    eng = pkg.Engine(w.plan, device=local, table_ptr=table.data_ptr() if table is not None else None)
     random_mode = w.plan.random_barcode
+    step_no = [0]
 
     def step():
         if random_mode:
             eng.clear_keys()  # a step is one whole job: otherwise every later step would see only duplicates
-        eng.submit_device(dseq.data_ptr(), qptr, n, R, R)
+        bs, bq = batches[step_no[0] % n_batches]
+        step_no[0] += 1
+        eng.submit_device(bs.data_ptr(), bq.data_ptr() if with_qual else None, n, R, R)
 
     def barrier():
         eng.sync()
@@ -250,11 +262,12 @@ def run_config(name, n, steps, warmup, world, rank, local, dev, legs):
     eng.sync()
     reset_ms = (time.perf_counter() - t_r) * 1e3
     eng.timing(True)
+    step_no[0] = 0
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
-    eng.sync()
+    eng.sync()  # (large dense tables: folds the first-occurrence bits into the table -- part of the job, inside the region)
     t_steps = time.perf_counter() - t0
     reduce_ms = 0.0
     fixed_counters = None
@@ -290,6 +303,7 @@ def run_config(name, n, steps, warmup, world, rank, local, dev, legs):
         avg_ms = kernel_ms / max(launches, 1)
         achieved = (b_alg * n) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         res = {"config": name, "workload": WORKLOAD_TEXT[name], "reads_per_step_per_gpu": n, "read_len": R,
+               "distinct_batches": n_batches,
                "value": total_reads / elapsed, "ms_per_step": elapsed * 1e3 / steps, "reduce_ms": reduce_ms,
                "reset_ms": reset_ms, "outcomes": {k: counters[k] for k in pkg.COUNTER_NAMES},
                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -313,6 +327,13 @@ def run_config(name, n, steps, warmup, world, rank, local, dev, legs):
             pass
 
     if rank == 0 and legs:
+        # ---- the job's end: compaction of the table into sparse rows on the host (bc_engine_finish) ----
+        if not random_mode:
+            t_f = time.perf_counter()
+            n_rows = eng.finish()
+            res["finish_ms"] = (time.perf_counter() - t_f) * 1e3
+            res["finish_rows"] = n_rows
+
         # ---- this box's own ceilings, measured after the timed region: boxes of the pool differ by up to ~20 % ----
         box = {}
         try:
@@ -328,26 +349,21 @@ def run_config(name, n, steps, warmup, world, rank, local, dev, legs):
             del dst
         except RuntimeError:
             pass
-        if table.numel():
-            # random no-return atomics (adds of 0: the counts stay as they are) over the whole counter table: the rate
-            # the memory system sustains for the kernel's counting alone
-            box["atomic_Gps"] = pkg.probe_atomic_rate(local, table.data_ptr(), table.numel(), 1 << 27) / 1e9
-            box["atomic_table_bytes"] = table.numel() * 4
+        if w.plan.table_entries:
+            # random no-return atomics over the whole counter table (+1, then -1 at the same entries: the counts end as they
+            # were): the rate the memory system sustains for plain counting alone
+            box["atomic_Gps"] = pkg.probe_atomic_rate(local, eng.table_ptr, w.plan.table_entries, 1 << 27) / 1e9
+            box["atomic_table_bytes"] = w.plan.table_entries * 4
         res["box"] = box
         res["roofline"]["box_copy_GBps"] = box.get("copy_GBps")
         res["roofline"]["frac_of_box_copy"] = (res["roofline"]["achieved"] / box["copy_GBps"]) if box.get("copy_GBps") else None
-
-        # ---- the job's end: compaction of the table into sparse rows on the host (bc_engine_finish) ----
-        if not random_mode:
-            t_f = time.perf_counter()
-            n_rows = eng.finish()
-            res["finish_ms"] = (time.perf_counter() - t_f) * 1e3
-            res["finish_rows"] = n_rows
 
         # ---- end to end: host buffers -> counts (bc_engine_submit_host: pinned double buffers, H2D on a side stream) ----
         m = min(n, 8_000_000)
         hs = dseq[:m * R].cpu().numpy()
         hq = dqual[:m * R].cpu().numpy() if with_qual else None
+        del batches[1:]
+        torch.cuda.empty_cache()
         eng.reset()
         eng.submit_host(hs[: 1_000_000 * R], hq[: 1_000_000 * R] if with_qual else None, R, R)  # staging buffers allocated
         eng.sync()
@@ -372,7 +388,7 @@ def run_config(name, n, steps, warmup, world, rank, local, dev, legs):
     if rank != 0:
         res = None
     eng.close()
-    del table, dseq, dqual
+    del table, dseq, dqual, batches
     torch.cuda.empty_cache()
     return res, w
 
@@ -432,6 +448,7 @@ def main():
         "dtype": "u8",
         "data": "synthetic",
         "config": {"workload": res["workload"], "config": args.config, "reads_per_step_per_gpu": n, "read_len": res["read_len"],
+                   "distinct_batches": res["distinct_batches"],
                    "parallelism": "reads sharded over %d GPU(s); one all-to-all sum of the counter tables over xGMI at the end" % world},
         "roofline": res["roofline"],
         "outcomes": res["outcomes"],
@@ -462,8 +479,8 @@ def main():
         extra = []
         for name in ("config2", "config4", "config5", "config5z"):
             r, _ = run_config(name, DEFAULT_READS[name], 3, 1, 1, 0, local, dev, False)
-            extra.append({k: r[k] for k in ("config", "workload", "reads_per_step_per_gpu", "value", "ms_per_step", "roofline",
-                                            "outcomes")})
+            extra.append({k: r[k] for k in ("config", "workload", "reads_per_step_per_gpu", "distinct_batches", "value",
+                                            "ms_per_step", "roofline", "outcomes")})
         out["extra"] = extra
     print(json.dumps(out))
     if world > 1:

@@ -553,7 +553,7 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
                                                  const uint8_t* __restrict__ qual, const uint16_t* __restrict__ lens,
                                                  const uint16_t* __restrict__ qlens,
                                                  uint32_t stride, uint32_t read_len, uint32_t nd, uint64_t n_reads,
-                                                 uint32_t region, uint32_t* __restrict__ table,
+                                                 uint32_t region, uint32_t* __restrict__ table, uint32_t* __restrict__ bits,
                                                  unsigned long long* __restrict__ slots, uint32_t* __restrict__ vals,
                                                  uint64_t smask, unsigned long long* __restrict__ counters,
                                                  uint8_t* __restrict__ trace_outcome, uint64_t* __restrict__ trace_idx,
@@ -622,6 +622,16 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
     ops.tile[i] = 'A';
     if (with_qual) ops.qtile[i] = 'I';
   }
+  // Two-level counting (`bits` given: large dense tables): the count of a tuple is bit + table entry.  A matched read
+  // first tries to set its tuple's bit in a one-bit-per-tuple map -- 32 times denser than the table, so a good part of
+  // it stays in the memory-side cache and a first occurrence costs no random 64-byte read and write-back of a table
+  // line in DRAM; only a read that finds its bit set already adds to the table.  The atomic OR has to return the old
+  // word: it is issued at the end of a tile and looked at one tile later (first_old / first_idx / first_on).
+  // Whichever way a read is counted the total stays exact (bit 0 -> 1, or table + 1), so the choice is free: a wave whose
+  // probes mostly find their bit set already (a batch counted twice, a library seen many times over) goes straight to the
+  // table for the next fifteen tiles and probes again on the sixteenth.
+  uint32_t first_old = 0, first_on = 0, direct_tiles = 0;
+  uint64_t first_idx = 0;
   uint64_t t = (uint64_t)blockIdx.x * (kTPB / 64) + wave;
   bool seq_ready = false, qual_ready = false;  // requested ahead of time
   if (t < n_full && pipe) {
@@ -688,6 +698,11 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
       trace_outcome[wfirst + lane] = (uint8_t)outcome;
       trace_idx[wfirst + lane] = pl.has_random ? r.dense_idx * pl.rspace + r.rcode : r.dense_idx;
     }
+    // the previous tile's first-occurrence probes, before anything new is requested (what is still in flight now was
+    // requested long ago): a bit that was set already makes the read a repeat, which goes to the table
+    bool repeat = false;
+    if (bits) repeat = first_on != 0u && ((first_old >> ((uint32_t)first_idx & 31u)) & 1u) != 0u;
+    const uint64_t repeat_idx = first_idx;
     // the quality region is free: request the next tile's quality lines (they have until that tile's
     // quality stage to arrive)
     seq_ready = next_full;
@@ -701,6 +716,16 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
     // when captures are kept raw, into the hash map slot of the tuple key.  Issued last so that the
     // fetches above are older: nothing in the next tile has to wait for the atomic to retire.
     ops.pending_add = 0;
+    if (bits) {
+      const uint32_t n_rep = (uint32_t)__popcll(__ballot(repeat));
+      if (n_rep) {
+        if (repeat) table_add(&table[repeat_idx]);
+        ops.pending_add += 1u;
+        if (2u * n_rep > (uint32_t)__popcll(__ballot(first_on != 0u))) direct_tiles = 16u;  // mostly repeats
+      }
+      if (direct_tiles) --direct_tiles;
+    }
+    first_on = 0u;
     if (!pl.has_random) {
       bool add = active && outcome == kMatched && !pl.discard_counts && !(pl.abl() & 0x4u);
       if (hot && !pl.sparse && __any(add)) {
@@ -719,16 +744,22 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
       }
       if (__any(add)) {
         if (add) {
-          if (pl.sparse)
+          if (pl.sparse) {
             atomicAdd(&vals[map_slot(slots, smask, r.dense_idx)], 1u);
-          else
+          } else if (bits && direct_tiles == 0u) {
+            first_old = atomicOr(&bits[r.dense_idx >> 5], 1u << ((uint32_t)r.dense_idx & 31u));
+            first_idx = r.dense_idx;
+            first_on = 1u;
+          } else {
             table_add(&table[r.dense_idx]);
+          }
         }
-        ops.pending_add = pl.sparse ? 0u : 1u;  // map_slot's compare-and-swap is waited for; the add is not
+        ops.pending_add += pl.sparse ? 0u : 1u;  // map_slot's compare-and-swap is waited for; the add is not
       }
     }
     ops.mark(9);
   }
+  if (bits && first_on != 0u && ((first_old >> ((uint32_t)first_idx & 31u)) & 1u) != 0u) table_add(&table[first_idx]);
 #ifdef BC_PROFILE
   if (lane == 0)
     for (int k = 0; k < 12; ++k) atomicAdd(&bc_g_profile[k], ops.acc[k]);

@@ -43,6 +43,28 @@ def test_config_sample_vs_oracle(name, n):
     eng.close()
 
 
+@pytest.mark.parametrize("n_sets,n", [((4, 30, 30, 30), 120_000), ((4, 200, 200, 200), 60_000)])
+def test_two_level_counting_vs_oracle(monkeypatch, n_sets, n):
+    """the first-occurrence bit map in front of the counter table (large dense tables; forced here for small ones): many
+    repeats per tuple and few, several submits with a fold between them (the streaming and the per-bit fold kernel),
+    every row against the oracle"""
+    import ngs_barcode_count_amd as pkg
+    monkeypatch.setenv("BC_BITMAP_MIN_ENTRIES", "1")
+    w = workloads.make("config3", n_sets=n_sets)
+    eng = pkg.Engine(w.plan, device=0)
+    _run(w, 0, n // 2, eng=eng, chunk=n // 6)
+    mid = eng.counters()  # syncs: folds the bits set so far into the table
+    assert mid["total_reads"] == n // 2
+    _run(w, n // 2, n - n // 2, eng=eng, chunk=n // 5)
+    seq, qual = w.synth.generate_host(0, n)
+    o = workloads.oracle_for(w)
+    o.process_batch(seq, qual, w.read_len, w.read_len)
+    got = eng.counters()
+    assert {k: got[k] for k in o.counters} == o.counters
+    assert eng.result_rows() == o.rows()
+    eng.close()
+
+
 def test_config4_random_barcode_vs_oracle():
     """config 4 shape: DEL + 12-nt random barcode, molecules drawn with repeats (mean 2 per molecule)"""
     n = 150000

@@ -22,6 +22,7 @@ ap.add_argument("--config", default="config3")
 ap.add_argument("--reads", type=int, default=0)
 ap.add_argument("--rounds", type=int, default=6)
 ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--fresh", action="store_true", help="reset the engine before every launch: every matched read is a first occurrence")
 ap.add_argument("libs", nargs="+")
 args = ap.parse_args()
 n = args.reads or {"config2": 10_000_000, "config3": 100_000_000, "config4": 50_000_000, "config5": 125_000_000}[args.config]
@@ -69,6 +70,11 @@ for r in range(args.rounds):
         for _ in range(args.steps):
             if w.plan.random_barcode:
                 eng.clear_keys()
+            if args.fresh:
+                eng.timing(False)
+                eng.reset()
+                eng.sync()
+                eng.timing(True)
             eng.submit_device(dseq.data_ptr(), qptr, n, w.read_len, w.read_len)
         ms, k = eng.kernel_ms()
         eng.timing(False)
