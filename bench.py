@@ -222,7 +222,9 @@ def run_config(name, n, steps, warmup, world, rank, local, dev, legs):
     # batches as the HBM holds next to the table; with more steps than that the batches are gone through again.
     batch_bytes = n * R * (2 if with_qual else 1)
     free_b, _ = torch.cuda.mem_get_info(dev)
-    n_batches = int(max(1, min(steps, (free_b - (12 << 30)) // batch_bytes)))
+    # (left free: the engine's table and bit map at N = 1; at N > 1 also the byte-packed slices of the table exchange)
+    spare = (24 << 30) if world == 1 else (48 << 30)
+    n_batches = int(max(1, min(steps, (free_b - spare) // batch_bytes)))
     first_read, _ = bcdist.shard(n * n_batches * world, rank, world)
     batches = []
     for k in range(n_batches):
