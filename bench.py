@@ -38,7 +38,7 @@ WORKLOAD_TEXT = {
     "config2": "DEL [8]+3x{8} vs 4 samples + 3x1000 refs, clean reads, exact match only (BASELINE configs[1])",
     "config3": "DEL [8]+3x{8} vs 4 samples + 3x1000 refs, 1% substitutions + 0.1% N, 20% mismatch budgets, "
                "--min-quality 20 (BASELINE configs[2])",
-    "config4": "DEL [8]+3x{8}+(12) random barcode vs 4 samples + 3x1000 refs, PCR duplicates (2 reads per molecule), "
+    "config4": "DEL [8]+3x{8}+(12) random barcode vs 4 samples + 3x1000 refs, PCR duplicates (copies per molecule geometric, mean 2), "
                "1% substitutions + 0.1% N (BASELINE configs[3], per-GPU shard of 50M reads; set cleared every step)",
     "config5": "CRISPR {20} vs 100k guides, 1% substitutions + 0.1% N, <=4 mismatches (BASELINE configs[4], per-GPU shard of 125M reads)",
     "config5z": "config5 with guide ranks drawn Zipf-like (P(k) ~ 1/k): the counter hot-spot variant of SURVEY.md 8(d)",
@@ -208,8 +208,12 @@ def run_config(name, n, steps, warmup, world, rank, local, dev, legs):
 
     if name == "config5z":
         w = workloads.make("config5", zipf=True)
+    elif name == "config4":
+        # PCR copies per molecule geometric with mean 2, scattered over one job = one step's reads of all ranks (the key
+        # set is cleared every step; every step draws the same molecules again with fresh sequencing errors)
+        w = workloads.make(name, geo_total=n * world)
     else:
-        w = workloads.make(name, n_molecules=(n * world) // 2 if name == "config4" else None)
+        w = workloads.make(name)
     R = w.read_len
     with_qual = w.min_quality > 0
     # N > 1: the counter table is this process's own tensor, so that it can be reduced with RCCL (allocated first: it is
@@ -314,7 +318,7 @@ def run_config(name, n, steps, warmup, world, rank, local, dev, legs):
                             "launches": launches, "kernel_reads_per_s": n / (avg_ms * 1e-3) if avg_ms > 0 else 0.0,
                             "sclk_mhz": sclk}}
         # HBM bytes per launch from the PMC counters (FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE),
-        # measured in separate rocprofv3 passes of this very workload (tools/scripts/tools_profile.sh) and committed
+        # measured in separate rocprofv3 passes of this very workload (tools/profile.sh) and committed
         # under profiles/; null when no summary of this config and size exists
         try:
             prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json"))

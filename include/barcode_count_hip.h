@@ -266,6 +266,8 @@ typedef struct bc_synth_params {
   uint32_t zipf;         /* 1: counted-barcode indices follow a Zipf-like law with exponent 1 (P(rank k) ~ 1/k; the
                             hot-spot variant of SURVEY.md 8(d)) instead of the uniform one */
   uint32_t reserved;
+  uint64_t geo_total;    /* > 0: PCR copies per molecule geometric with mean 2, scattered over this many reads (the
+                            job's total) by a fixed permutation; n_molecules is then ignored */
 } bc_synth_params;
 
 bc_synth *bc_synth_create(const bc_plan *p, const bc_synth_params *params);

@@ -279,12 +279,12 @@ class Synth:
     """Counter-based synthetic read generator; identical on host and device."""
 
     def __init__(self, plan, seed, read_len=100, p_sub=0.0, p_n=0.0, p_lowq=0.0, phred=(30, 40), lowq=(2, 15),
-                 n_molecules=0, zipf=False):
+                 n_molecules=0, zipf=False, geo_total=0):
         self._lib = plan._lib
         self.plan = plan
         f = lambda p: min(int(round(p * 4294967296.0)), 4294967295)
         self.params = SynthParams(seed, read_len, f(p_sub), f(p_n), f(p_lowq), phred[0], phred[1], lowq[0], lowq[1],
-                                  n_molecules, 1 if zipf else 0, 0)
+                                  n_molecules, 1 if zipf else 0, 0, geo_total)
         self._s = self._lib.bc_synth_create(plan._p, C.byref(self.params))
         if not self._s:
             raise BarcodeCountError(_lib.BC_ERR_INVALID, _lib.last_error(self._lib))

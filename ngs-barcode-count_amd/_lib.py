@@ -15,7 +15,7 @@ COUNTER_NAMES = ["matched", "constant_region", "sample_barcode", "barcode", "dup
 class SynthParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("read_len", C.c_uint32), ("p_sub", C.c_uint32), ("p_n", C.c_uint32),
                 ("p_lowq", C.c_uint32), ("phred_lo", C.c_uint8), ("phred_hi", C.c_uint8), ("lowq_lo", C.c_uint8),
-                ("lowq_hi", C.c_uint8), ("n_molecules", C.c_uint64), ("zipf", C.c_uint32), ("reserved", C.c_uint32)]
+                ("lowq_hi", C.c_uint8), ("n_molecules", C.c_uint64), ("zipf", C.c_uint32), ("reserved", C.c_uint32), ("geo_total", C.c_uint64)]
 
 
 _vp, _cp, _u32, _u64, _i32, _int, _sz = C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint64, C.c_int32, C.c_int, C.c_size_t

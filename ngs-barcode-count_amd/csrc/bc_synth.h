@@ -29,6 +29,8 @@ struct SynthDev {
   uint32_t phred_lo, phred_hi, lowq_lo, lowq_hi;
   uint64_t n_molecules;
   uint32_t zipf;                 // counted-barcode indices drawn octave-uniformly (P(k) ~ 1/k) instead of uniformly
+  uint64_t geo_total;            // > 0: PCR copies per molecule geometric with mean 2 (P(c) = 2^-c), the copies scattered
+                                 // over the geo_total reads of the job by a fixed permutation
   uint32_t n_groups;
   uint32_t n_sb;                 // groups that can receive low qualities (sample + counted)
   SynthGroup groups[kMaxGroups];
@@ -57,10 +59,43 @@ struct SynthRead {
   uint64_t rnd_bits[kMaxGroups];
 };
 
+// a fixed bijection of [0, n): multiply / xor-shift / multiply on the next power of two, walked until it lands below n
+BC_HD uint64_t synth_permute(uint64_t x, uint64_t n, uint64_t seed) {
+  uint32_t k = 1;
+  while ((1ull << k) < n) ++k;
+  const uint64_t mask = k >= 64 ? ~0ull : ((1ull << k) - 1ull);
+  const uint64_t a = (seed * 2ull + 0x9E3779B97F4A7C15ull) | 1ull, b = (seed * 6ull + 0xD1B54A32D192ED03ull) | 1ull;
+  do {
+    x = (x * a) & mask;
+    x ^= x >> ((k + 1) / 2);
+    x = (x * b + seed) & mask;
+    x ^= x >> ((k + 1) / 2);
+  } while (x >= n);
+  return x;
+}
+
+// Molecule of slot j when every molecule has 1 + Geometric(1/2) copies (mean 2): slots come in blocks of 128 shared by
+// 64 molecules; molecule m of a block has as many copies as its hash has trailing zeros, plus one; the block's last
+// molecule takes what is left (or nothing).  No prefix sum over the job: 63 hashes at most.
+BC_HD uint64_t synth_geo_molecule(uint64_t seed, uint64_t j) {
+  const uint64_t block = j >> 7;
+  const uint32_t r = (uint32_t)(j & 127u);
+  uint32_t upto = 0, m = 0;
+  for (; m < 63u; ++m) {
+    const uint64_t h = synth_mix(seed ^ 0x6E0C0FFEEull, block, m) | (1ull << 40);
+    uint32_t c = 1;
+    for (uint64_t t = h; !(t & 1ull); t >>= 1) ++c;
+    upto += c;
+    if (r < upto) break;
+  }
+  return block * 64ull + m;
+}
+
 BC_HD void synth_begin(const SynthDev& S, uint64_t i, SynthRead& R) {
   const uint32_t slack = S.read_len > S.L ? S.read_len - S.L : 0u;
   R.off = slack ? (uint32_t)(synth_mix(S.seed, i, 0) % slack) : 0u;  // uniform in [0, R-L-1]
   R.mol = S.n_molecules ? synth_mix(S.seed, i, 1) % S.n_molecules : i;
+  if (S.geo_total) R.mol = synth_geo_molecule(S.seed, synth_permute(i % S.geo_total, S.geo_total, S.seed));
   const uint64_t hl = synth_mix(S.seed, i, 2);
   R.lowq_group = -1;
   if ((uint32_t)hl < S.p_lowq && S.n_sb) {

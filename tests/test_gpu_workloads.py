@@ -81,9 +81,15 @@ def test_config4_random_barcode_vs_oracle():
     eng.close()
 
 
-def test_synth_device_equals_host():
+@pytest.mark.parametrize("variant", ["config3", "geometric", "zipf"])
+def test_synth_device_equals_host(variant):
     import torch
-    w = workloads.make("config3", n_sets=(4, 100, 100, 100))
+    if variant == "geometric":
+        w = workloads.make("config4", n_sets=(4, 100, 100, 100), geo_total=1 << 40)
+    elif variant == "zipf":
+        w = workloads.make("config5", n_sets=(5000,), zipf=True)
+    else:
+        w = workloads.make("config3", n_sets=(4, 100, 100, 100))
     n = 5000
     seq, qual = w.synth.generate_host(123456789012, n)
     dseq = torch.empty(n * 100, dtype=torch.uint8, device="cuda")

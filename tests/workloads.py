@@ -12,7 +12,7 @@ class Workload:
     pass
 
 
-def make(name, n_sets=None, lib=None, n_molecules=None, read_len=100, zipf=False):
+def make(name, n_sets=None, lib=None, n_molecules=None, read_len=100, zipf=False, geo_total=0):
     """name: config2 | config3 | config5.  n_sets = (samples, refs per counted barcode...) overrides the
     BASELINE sizes (tests use smaller sets so the CPU oracle stays fast)."""
     w = Workload()
@@ -53,7 +53,9 @@ def make(name, n_sets=None, lib=None, n_molecules=None, read_len=100, zipf=False
             for i, s in enumerate(refs):
                 plan.add_counted(b, s, "bb%d_%d" % (b + 1, i))
         w.kwargs = {}
-        w.synth_args = dict(seed=4, p_sub=0.01, p_n=0.001, n_molecules=n_molecules or 200_000_000)
+        # geo_total (the job's read count): copies per molecule geometric with mean 2, scattered over the job -- the
+        # SURVEY.md 8(d) model; without it reads are uniform draws from n_molecules molecules (Poisson copies)
+        w.synth_args = dict(seed=4, p_sub=0.01, p_n=0.001, n_molecules=n_molecules or 200_000_000, geo_total=geo_total)
         w.min_quality = 0.0
     elif name == "config5":
         sizes = n_sets or (100000,)
