@@ -110,6 +110,11 @@ struct DevGroup {
   uint32_t lhash_off;       // first bucket of this group in the workgroup's table area (16-byte units)
   uint32_t lhash_complete;
   uint32_t index;           // position in DevPlan::groups
+  // tier_bkt in its compact form: four 8-byte entries per bucket (32 bytes: the whole first tier of 100 k 20-nt
+  // guides is 4 MiB and mostly stays in the XCD's L2) -- entry = r1 | r2 << len | index << 2 len, the bucket's
+  // reference count (capped at 7) in the top three bits of its first entry.  0: sixteen-byte entries.
+  uint32_t tier_compact;
+  uint32_t pad_;
 
   BC_HD const BC_GLOBAL uint32_t* dtable() const { return reinterpret_cast<const BC_GLOBAL uint32_t*>(BC_ADDR(dtable_a, 0)); }
   BC_HD const BC_GLOBAL uint32_t* r1() const { return reinterpret_cast<const BC_GLOBAL uint32_t*>(BC_ADDR(r1_a, 1)); }

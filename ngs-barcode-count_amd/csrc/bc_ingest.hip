@@ -682,7 +682,7 @@ extern "C" int bc_fastq_count(bc_engine* e, const char* fastq_path, uint64_t* to
       rc = in.submit(pending % kSlots, &n_rec);
       if (rc != BC_OK) break;
       total += n_rec;
-      if (progress && n_rec) progress(total, user);
+      if (progress && n_rec) progress(total - total % 10000, user);  // the reference prints every 10,000 reads (input.rs:54-57)
       {
         const ChunkStats& cs = *in.slot[pending % kSlots].stats;
         lines_after_last_record = cs.n_lines - 4 * cs.n_rec;
@@ -699,7 +699,7 @@ extern "C" int bc_fastq_count(bc_engine* e, const char* fastq_path, uint64_t* to
         rc = in.submit(pending % kSlots, &n_rec);
         if (rc != BC_OK) break;
         total += n_rec;
-        if (progress && n_rec) progress(total, user);
+        if (progress && n_rec) progress(total - total % 10000, user);  // the reference prints every 10,000 reads (input.rs:54-57)
         const ChunkStats& cs = *in.slot[pending % kSlots].stats;
         lines_after_last_record = cs.n_lines - 4 * cs.n_rec;
       }

@@ -870,18 +870,36 @@ BC_HD uint32_t single_n_lhash(const Quad* __restrict__ area, uint32_t off, uint3
 BC_HD void tier_probe(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t& best, uint32_t& cnt, uint32_t& idx) {
   const uint32_t blen = G.tier_blen, bm = (1u << blen) - 1u, nbk = 1u << (2u * blen);
   const BC_GLOBAL uint32_t* bkt = G.tier_bkt();
-  // both buckets' heads (a 64-byte line each) are requested before either is looked at: one round trip
+  // both buckets' heads (one line each) are requested before either is looked at: one round trip
   uint32_t val[2];
-  uint32_t e[2][4][4];
+  uint32_t e[2][4][4];  // [block][entry]{r1, r2, index, references in the bucket}
 #pragma unroll
   for (uint32_t b = 0; b < 2; ++b) {
     const uint32_t sh = b * G.tier_stride;
     val[b] = ((q1 >> sh) & bm) | (((q2 >> sh) & bm) << blen);
-    const BC_GLOBAL uint32_t* line = bkt + ((size_t)b * nbk + val[b]) * 16u;
+    if (G.tier_compact) {
+      // 32 bytes: four entries of r1 | r2 << len | index << 2 len, the count in the first one's top three bits
+      const BC_GLOBAL uint32_t* line = bkt + ((size_t)b * nbk + val[b]) * 8u;
+      uint32_t w[8];
 #pragma unroll
-    for (uint32_t k = 0; k < 4; ++k)
+      for (uint32_t c = 0; c < 8; ++c) w[c] = line[c];
+      const uint32_t len = G.len, lm = lowmask(len);
 #pragma unroll
-      for (uint32_t c = 0; c < 4; ++c) e[b][k][c] = line[k * 4u + c];
+      for (uint32_t k = 0; k < 4; ++k) {
+        const uint64_t x = ((uint64_t)w[2 * k + 1] << 32) | w[2 * k];
+        e[b][k][0] = (uint32_t)x & lm;
+        e[b][k][1] = (uint32_t)(x >> len) & lm;
+        e[b][k][2] = (uint32_t)((x & 0x1FFFFFFFFFFFFFFFull) >> (2u * len));
+        e[b][k][3] = 0;
+      }
+      e[b][0][3] = w[1] >> 29;
+    } else {
+      const BC_GLOBAL uint32_t* line = bkt + ((size_t)b * nbk + val[b]) * 16u;
+#pragma unroll
+      for (uint32_t k = 0; k < 4; ++k)
+#pragma unroll
+        for (uint32_t c = 0; c < 4; ++c) e[b][k][c] = line[k * 4u + c];
+    }
   }
   best = 0xFFFFFFFFu;
   cnt = 0;
@@ -901,7 +919,7 @@ BC_HD void tier_probe(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t& bes
   };
 #pragma unroll
   for (uint32_t b = 0; b < 2; ++b) {
-    const uint32_t n = e[b][0][3];
+    const uint32_t n = e[b][0][3];  // (compact form: capped at 7, which is all the test below needs)
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k) score(e[b][k][0], e[b][k][1], e[b][k][2], b == 1u, k < n);
     if (n > 4u) {  // the rest of a long bucket

@@ -433,6 +433,29 @@ bool bc_plan::lower(HostDevPlan& out) const {
           }
           G.tier_blen = tb;
           G.tier_stride = stride;
+          // compact form when an entry fits 61 bits (bc_device_plan.h)
+          uint32_t idx_bits = 1;
+          while ((1ull << idx_bits) < (uint64_t)G.n_refs) ++idx_bits;
+          if (2u * G.len + idx_bits <= 61u) {
+            std::vector<uint32_t> compact((size_t)2 * tnbk * 8, 0);
+            for (uint32_t b = 0; b < 2; ++b) {
+              for (uint32_t v = 0; v < tnbk; ++v) {
+                const uint32_t* line = &H.tier_bkt[((size_t)b * tnbk + v) * 16];
+                uint32_t* out8 = &compact[((size_t)b * tnbk + v) * 8];
+                const uint32_t n = line[3];
+                for (uint32_t k = 0; k < 4; ++k) {
+                  uint64_t e = (uint64_t)line[k * 4 + 0] | ((uint64_t)line[k * 4 + 1] << G.len) |
+                               ((uint64_t)line[k * 4 + 2] << (2u * G.len));
+                  if (k >= n) e = 0;
+                  if (k == 0) e |= (uint64_t)std::min<uint32_t>(n, 7u) << 61;
+                  out8[k * 2] = (uint32_t)e;
+                  out8[k * 2 + 1] = (uint32_t)(e >> 32);
+                }
+              }
+            }
+            H.tier_bkt.swap(compact);
+            G.tier_compact = 1;
+          }
         }
       }
     }
