@@ -157,7 +157,8 @@ __device__ __forceinline__ bool wave_scan_blocks_wide(uint32_t nb, uint32_t blen
   return kmin != 0xFFFFFFFFu && kmin <= nb;  // key = distance + 1
 }
 
-__device__ __forceinline__ void wave_seeded_min(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t& kmin_out,
+// coarse_done: the coarse index has been asked already (coarse_probe_x4) and could not decide
+__device__ __forceinline__ void wave_seeded_min(const DevGroup& G, uint32_t q1, uint32_t q2, bool coarse_done, uint32_t& kmin_out,
                                                 bool& unique_out, uint32_t& idx_out) {
   const uint32_t lane = __lane_id();
   Nearest s;
@@ -165,7 +166,7 @@ __device__ __forceinline__ void wave_seeded_min(const DevGroup& G, uint32_t q1, 
   // the coarse index decides whenever some reference is within two mismatches (its three long blocks
   // make for short buckets); only otherwise is the full one, with its budget + 1 short blocks, walked
   bool decided = false;
-  if (G.seed2_nb) decided = wave_scan_blocks_wide<3>(G.seed2_nb, G.seed2_blen, G.seed2_off(), G.seed2_list(), G.n_idx, q1, q2, s);
+  if (G.seed2_nb && !coarse_done) decided = wave_scan_blocks_wide<3>(G.seed2_nb, G.seed2_blen, G.seed2_off(), G.seed2_list(), G.n_idx, q1, q2, s);
   if (!decided) {
     nearest_init(s);  // whatever the coarse pass met is met again
     wave_scan_blocks(G.seed_nb, G.seed_blen, G.seed_off(), G.seed_list(), G.n_idx, q1, q2, s);
@@ -190,8 +191,23 @@ __device__ __forceinline__ void wave_seeded_min(const DevGroup& G, uint32_t q1, 
 // calling lane's segment; seg_on = that segment has one.  Per segment: the smallest key (distance + 1, 0 for the
 // capture itself), whether exactly one reference has it, that reference -- valid when kmin <= nb (decided, as in
 // wave_scan_blocks_wide); otherwise the full index has to be walked for that capture.
-__device__ __forceinline__ void coarse_probe_x4(const DevGroup& G, uint32_t q1, uint32_t q2, bool seg_on, uint32_t& kmin_out,
-                                                bool& unique_out, uint32_t& idx_out) {
+struct CoarseVote {
+  uint32_t kmin;                      // the segment's smallest key
+  unsigned long long holders, single; // lanes holding it / holding it with exactly one reference
+  uint32_t idx_lane;                  // this lane's reference
+};
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, int lane_index) {  // lane_index: the same in every lane
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, lane_index);
+}
+// segment k of a vote: smallest key, whether exactly one reference has it, that reference (scalar work only)
+__device__ __forceinline__ void coarse_segment(const CoarseVote& c, int k, uint32_t& kmin, bool& unique, uint32_t& idx) {
+  kmin = rdlane(c.kmin, 16 * k);
+  const uint32_t hm = (uint32_t)(c.holders >> (16 * k)) & 0xFFFFu, sm = (uint32_t)(c.single >> (16 * k)) & 0xFFFFu;
+  const int first = 16 * k + (hm ? __ffs((int)hm) - 1 : 0);
+  idx = rdlane(c.idx_lane, first);
+  unique = __popc(hm) == 1 && sm == hm && kmin != 0xFFFFFFFFu;
+}
+__device__ __forceinline__ void coarse_probe_x4(const DevGroup& G, uint32_t q1, uint32_t q2, bool seg_on, CoarseVote& vote) {
   constexpr int kMaxBlocks = 3;
   const uint32_t nb = G.seed2_nb, blen = G.seed2_blen, n_idx = G.n_idx;
   const uint32_t bm = (1u << blen) - 1u;
@@ -217,36 +233,46 @@ __device__ __forceinline__ void coarse_probe_x4(const DevGroup& G, uint32_t q1, 
     for (uint32_t p = 0; p < b; ++p) earlier = earlier || ((diff >> (p * blen)) & bm) == 0u;
     if (on && !earlier) nearest_add(s, popc(diff), x.z, diff == 0u);
   };
-  uint4 e[kMaxBlocks];
+  // the first thirty-two entries of every bucket in one round trip (a bucket of the 100 k x 20-nt index holds two
+  // dozen); longer buckets finish in a loop
+  uint4 e[kMaxBlocks][2];
 #pragma unroll
-  for (int b = 0; b < kMaxBlocks; ++b) {  // the first sixteen entries of every bucket: one round trip
-    const uint32_t i = beg[b] + j;
-    e[b] = make_uint4(0, 0, 0, 0);
-    if (i < end[b]) e[b] = entries[(size_t)b * n_idx + i];
+  for (int b = 0; b < kMaxBlocks; ++b) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const uint32_t i = beg[b] + j + 16u * t;
+      e[b][t] = make_uint4(0, 0, 0, 0);
+      if (i < end[b]) e[b][t] = entries[(size_t)b * n_idx + i];
+    }
   }
 #pragma unroll
   for (int b = 0; b < kMaxBlocks; ++b) {
-    score(e[b], (uint32_t)b, beg[b] + j < end[b]);
-    for (uint32_t i = beg[b] + 16u + j; __any(i - j < end[b]); i += 16u) {  // longer buckets (wave-uniform trip count)
+    score(e[b][0], (uint32_t)b, beg[b] + j < end[b]);
+    score(e[b][1], (uint32_t)b, beg[b] + j + 16u < end[b]);
+    for (uint32_t i = beg[b] + 32u + j; __any(i - j < end[b]); i += 16u) {  // (wave-uniform trip count)
       const bool on = i < end[b];
       uint4 x = make_uint4(0, 0, 0, 0);
       if (on) x = entries[(size_t)b * n_idx + i];
       score(x, (uint32_t)b, on);
     }
   }
+  // minimum over the segment's sixteen lanes: rotations within the row (DPP), no trip through the LDS crossbar
   uint32_t kmin = s.key;
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) {  // minimum over the segment's sixteen lanes
-    const uint32_t t = (uint32_t)__shfl_xor((int)kmin, o);
+  {
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)kmin, 0x128 /* row_ror:8 */, 0xF, 0xF, false);
+    kmin = t < kmin ? t : kmin;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)kmin, 0x124 /* row_ror:4 */, 0xF, 0xF, false);
+    kmin = t < kmin ? t : kmin;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)kmin, 0x122 /* row_ror:2 */, 0xF, 0xF, false);
+    kmin = t < kmin ? t : kmin;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)kmin, 0x121 /* row_ror:1 */, 0xF, 0xF, false);
     kmin = t < kmin ? t : kmin;
   }
-  const unsigned long long holders = __ballot(s.key == kmin);
-  const uint32_t seg_mask = (uint32_t)(holders >> (lane & 48u)) & 0xFFFFu;  // never empty: the minimum has a holder
-  const int first = (int)(lane & 48u) + (__ffs(seg_mask) - 1);
-  const uint32_t cnt = (uint32_t)__shfl((int)s.count, first);
-  idx_out = (uint32_t)__shfl((int)s.idx, first);
-  unique_out = __popc(seg_mask) == 1 && cnt == 1u && kmin != 0xFFFFFFFFu;
-  kmin_out = kmin;
+  vote.kmin = kmin;
+  vote.holders = __ballot(s.key == kmin);
+  vote.single = __ballot(s.key == kmin && s.count == 1u);
+  vote.idx_lane = s.idx;
 }
 
 // A capture with up to two 'N's against plain references: 'N' is free (parse.rs:569), so its
@@ -254,7 +280,8 @@ __device__ __forceinline__ void coarse_probe_x4(const DevGroup& G, uint32_t q1, 
 // there.  The nearest references of the capture are therefore those of its 4 (16) substitutions
 // at the smallest of their minimum distances, and the match is unique iff exactly one substitution
 // reaches that distance and does so uniquely (the argument of single_n_lookup, bc_lane.h).
-__device__ __forceinline__ uint32_t wave_fix_error_seeded(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t qn) {
+__device__ __forceinline__ uint32_t wave_fix_error_seeded(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t qn,
+                                                          bool coarse_done = false) {
   const uint32_t n_n = popc(qn);
   const uint32_t p0 = n_n ? ctz(qn) : 0u;
   const uint32_t p1 = n_n > 1 ? ctz(qn & (qn - 1u)) : 0u;
@@ -274,7 +301,7 @@ __device__ __forceinline__ uint32_t wave_fix_error_seeded(const DevGroup& G, uin
     }
     uint32_t k, idx;
     bool uniq;
-    wave_seeded_min(G, s1, s2, k, uniq, idx);
+    wave_seeded_min(G, s1, s2, coarse_done, k, uniq, idx);
     if (k < best) {
       best = k;
       ok = uniq;
@@ -463,6 +490,8 @@ struct DeviceOps {
   bool qual_async;        // this tile's quality lines were requested ahead of time
 
   __device__ __forceinline__ bool any(bool c) const { return __any(c) != 0; }
+  uint32_t abl_;  // experiment switches (0 outside BC_EXPERIMENT builds)
+  __device__ __forceinline__ void issued() const { asm volatile("" ::: "memory"); }
   // the sequence bytes are dead once the planes are built: the next tile's sequence lines can land
   __device__ __forceinline__ void sequence_consumed() const {
     wave_lds_fence();
@@ -484,15 +513,125 @@ struct DeviceOps {
     wave_lds_fence();
     return reinterpret_cast<const uint32_t*>(qtile);
   }
+  // tier_lookup_single_n (bc_lane.h) for the lanes that `want` it, two captures per pass: the 4 substitutions x 2
+  // blocks x 4 bucket-head entries of one capture are 32 lanes' worth of one load, so a capture costs one round trip
+  // of half the wave instead of four of all of it.  Every lane calls this.
+  __device__ __forceinline__ uint32_t tier_single_n(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t qn, bool want,
+                                                    bool& settled) const {
+    uint32_t out = kFail;
+    settled = false;
+    unsigned long long todo = __ballot(want);
+    const uint32_t blen = G.tier_blen, bm = (1u << blen) - 1u, nbk = 1u << (2u * blen);
+    const BC_GLOBAL uint32_t* bkt = G.tier_bkt();
+    const uint32_t half = lane >> 5, sub = (lane >> 3) & 3u, blk = (lane >> 2) & 1u, ent = lane & 3u;
+    while (todo) {
+      const int s0 = __ffsll(todo) - 1;
+      todo &= todo - 1;
+      int s1 = s0;
+      const bool two = todo != 0;
+      if (two) {
+        s1 = __ffsll(todo) - 1;
+        todo &= todo - 1;
+      }
+      const bool on = half == 0u || two;
+      // (lane indices that are the same for the whole wave: v_readlane instead of a trip through the LDS crossbar)
+      const uint32_t b1 = half ? rdlane(q1, s1) : rdlane(q1, s0), b2 = half ? rdlane(q2, s1) : rdlane(q2, s0);
+      const uint32_t bn = half ? rdlane(qn, s1) : rdlane(qn, s0);
+      const uint32_t k = bn ? ctz(bn) : 0u;
+      const uint32_t c1 = (b1 & ~bn) | ((sub & 1u) << k), c2 = (b2 & ~bn) | ((sub >> 1) << k);
+      const uint32_t sh = blk * G.tier_stride;
+      const uint32_t val = ((c1 >> sh) & bm) | (((c2 >> sh) & bm) << blen);
+      uint32_t r1, r2, j, n_here;
+      if (G.tier_compact) {
+        const BC_GLOBAL uint32_t* line = bkt + ((size_t)blk * nbk + val) * 8u;
+        const uint2 wv = *reinterpret_cast<const BC_GLOBAL uint2*>(line + 2u * ent);  // one load, not one per word
+        const uint32_t w0 = wv.x, w1 = wv.y;
+        const uint32_t len = G.len, lm = lowmask(len);
+        const uint64_t x = ((uint64_t)w1 << 32) | w0;
+        r1 = (uint32_t)x & lm;
+        r2 = (uint32_t)(x >> len) & lm;
+        j = (uint32_t)((x & 0x1FFFFFFFFFFFFFFFull) >> (2u * len));
+        n_here = w1 >> 29;
+      } else {
+        const uint4 e = *reinterpret_cast<const BC_GLOBAL uint4*>(bkt + ((size_t)blk * nbk + val) * 16u + 4u * ent);
+        r1 = e.x;
+        r2 = e.y;
+        j = e.z;
+        n_here = e.w;
+      }
+      const uint32_t n = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n_here, 0 /* quad_perm:[0,0,0,0] */, 0xF, 0xF, false);
+      const uint32_t diff = (c1 ^ r1) | (c2 ^ r2);
+      // a reference that equals the substitution on block 0 too was met there
+      const bool use = on && ent < n && !(blk == 1u && (diff & bm) == 0u);
+      uint32_t d = use ? (uint32_t)__popc(diff) : 0xFFFFFFFFu;
+      uint32_t held = 1;  // references this lane has met at distance d
+      if (__any(on && n > 4u)) {
+        // the rest of a long bucket: its four lanes walk the list, four entries per round trip
+        uint32_t i = 0, end = 0;
+        if (on && n > 4u) {
+          const BC_GLOBAL uint32_t* off = G.tier_off() + (size_t)blk * (nbk + 1u);
+          i = off[val] + 4u + ent;
+          end = off[val + 1u];
+        }
+        const BC_GLOBAL uint32_t* list = G.tier_list() + (size_t)blk * G.n_idx * 4u;
+        while (__any(i < end)) {
+          if (i < end) {
+            const uint4 le = *reinterpret_cast<const BC_GLOBAL uint4*>(list + (size_t)i * 4u);
+            const uint32_t l1 = le.x, l2 = le.y, lj = le.z;
+            const uint32_t df = (c1 ^ l1) | (c2 ^ l2);
+            if (!(blk == 1u && (df & bm) == 0u)) {
+              const uint32_t dd = (uint32_t)__popc(df);
+              if (dd < d) {
+                d = dd;
+                j = lj;
+                held = 1;
+              } else if (dd == d) {
+                ++held;
+              }
+            }
+          }
+          i += 4u;
+        }
+      }
+      // only distances 0 and 1 settle a capture: two votes instead of a minimum over the lanes
+      const unsigned long long z0 = __ballot(d == 0u), z1 = __ballot(d == 1u);
+      uint32_t res_h[2];
+      bool sett_h[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const uint32_t zh0 = (uint32_t)(z0 >> (32 * h)), zh1 = (uint32_t)(z1 >> (32 * h));
+        const uint32_t m = zh0 ? 0u : (zh1 ? 1u : 2u);
+        const uint32_t hb = zh0 ? zh0 : zh1;
+        const int first = hb ? (__ffs((int)hb) - 1 + 32 * h) : 0;
+        const uint32_t idx = rdlane(j, first);
+        const bool one = __popc(hb) == 1 && rdlane(held, first) == 1u;
+        sett_h[h] = m <= 1u;
+        res_h[h] = (sett_h[h] && one && m <= G.max_err) ? idx : kFail;
+      }
+      const uint32_t res0 = res_h[0], res1 = res_h[1];
+      const bool sett0 = sett_h[0], sett1 = sett_h[1];
+      if ((int)lane == s0) {
+        out = res0;
+        settled = sett0;
+      }
+      if (two && (int)lane == s1) {
+        out = res1;
+        settled = sett1;
+      }
+    }
+    return out;
+  }
   // every lane calls this; lanes with `need` get their capture resolved one after the other
   __device__ __forceinline__ uint32_t nearest(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t qn, uint32_t qx,
                                               bool need) const {
     uint32_t out = kFail;
     unsigned long long todo = __ballot(need);
+    unsigned long long probed = 0;  // captures the coarse index has been asked about
     if (G.seed_nb && G.seed2_nb && G.seed2_nb <= 3u && G.n_odd == 0u) {
       // plain captures (no 'N', no foreign byte) four at a time through the coarse index; what it cannot decide (the
       // nearest reference is three or more mismatches away, or there is none) stays in `todo` for the full search
       unsigned long long plain = __ballot(need && qn == 0u && qx == 0u);
+      probed |= plain;
       while (plain) {
         int src[4];
         int n_seg = 0;
@@ -505,27 +644,79 @@ struct DeviceOps {
           }
         }
         const uint32_t seg = lane >> 4;
-        const int my_src = seg == 0u ? src[0] : (seg == 1u ? src[1] : (seg == 2u ? src[2] : src[3]));
         const bool seg_on = (int)seg < n_seg;
-        const uint32_t b1 = (uint32_t)__shfl((int)q1, my_src);
-        const uint32_t b2 = (uint32_t)__shfl((int)q2, my_src);
-        uint32_t kmin, idx;
-        bool uniq;
-        coarse_probe_x4(G, b1, b2, seg_on, kmin, uniq, idx);
-        const bool decided = seg_on && kmin != 0xFFFFFFFFu && kmin <= G.seed2_nb;
-        const uint32_t res = (uniq && (kmin == 0u || kmin - 1u <= G.max_err)) ? idx : kFail;
+        // (lane indices that are the same for the whole wave: v_readlane, not the LDS crossbar)
+        uint32_t b1 = rdlane(q1, src[0]), b2 = rdlane(q2, src[0]);
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+          const uint32_t t1 = rdlane(q1, src[k]), t2 = rdlane(q2, src[k]);
+          b1 = seg == (uint32_t)k ? t1 : b1;
+          b2 = seg == (uint32_t)k ? t2 : b2;
+        }
+        CoarseVote vote;
+        coarse_probe_x4(G, b1, b2, seg_on, vote);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           if (k >= n_seg) break;
-          const bool d_k = __shfl((int)decided, 16 * k) != 0;
-          const uint32_t r_k = (uint32_t)__shfl((int)res, 16 * k);
-          if (d_k) {
-            if ((int)lane == src[k]) out = r_k;
+          uint32_t kmin, idx;
+          bool uniq;
+          coarse_segment(vote, k, kmin, uniq, idx);
+          if (kmin != 0xFFFFFFFFu && kmin <= G.seed2_nb) {  // decided
+            if ((int)lane == src[k]) out = (uniq && (kmin == 0u || kmin - 1u <= G.max_err)) ? idx : kFail;
             todo &= ~(1ull << src[k]);
           }
         }
       }
     }
+    if (G.seed_nb && G.seed2_nb && G.seed2_nb <= 3u && G.n_odd == 0u) {
+      // captures with one to four 'N's: their 4 .. 256 substitutions (wave_fix_error_seeded) are four plain captures per
+      // pass of the same coarse probe -- a capture with three 'N's, one in a million, would otherwise hold its
+      // wavefront for milliseconds in the scan of the whole set.  A substitution the probe decides (key <= blocks) has
+      // its true minimum and count; one it cannot decide has nothing that near, so any decided substitution settles
+      // the capture.
+      unsigned long long with_n = __ballot(need && qx == 0u && qn != 0u && __popc(qn) <= 4);
+      probed |= with_n;
+      while (with_n) {
+        const int src = __ffsll(with_n) - 1;
+        with_n &= with_n - 1;
+        const uint32_t b1 = rdlane(q1, src), b2 = rdlane(q2, src), bn = rdlane(qn, src);
+        const uint32_t n_n = (uint32_t)__popc(bn);
+        const uint32_t combos = 1u << (2u * n_n);
+        uint32_t best = 0xFFFFFFFFu, res = kFail;
+        bool ok = false, any_decided = false;
+        for (uint32_t c0 = 0; c0 < combos; c0 += 4u) {
+          const uint32_t c = c0 + (lane >> 4);
+          uint32_t s1 = b1 & ~bn, s2 = b2 & ~bn;
+          for (uint32_t t = 0, rem = bn; rem; ++t, rem &= rem - 1u) {  // base (c >> 2t) & 3 at the t-th 'N'
+            s1 |= ((c >> (2u * t)) & 1u) << ctz(rem);
+            s2 |= ((c >> (2u * t + 1u)) & 1u) << ctz(rem);
+          }
+          CoarseVote vote;
+          coarse_probe_x4(G, s1, s2, true, vote);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            uint32_t kk, ii;
+            bool uu;
+            coarse_segment(vote, k, kk, uu, ii);
+            if (kk <= G.seed2_nb) {
+              any_decided = true;
+              if (kk < best) {
+                best = kk;
+                ok = uu;
+                res = ii;
+              } else if (kk == best) {
+                ok = false;
+              }
+            }
+          }
+        }
+        if (any_decided) {
+          if ((int)lane == src) out = (ok && (best == 0u || best - 1u <= G.max_err)) ? res : kFail;
+          todo &= ~(1ull << src);
+        }
+      }
+    }
+    if (abl_ & 0x100000u) todo &= ~probed;  // experiment: what the coarse index cannot decide simply fails
     while (todo) {
       const int src = __ffsll(todo) - 1;
       todo &= todo - 1;
@@ -535,7 +726,8 @@ struct DeviceOps {
       const uint32_t bx = (uint32_t)__shfl((int)qx, src);
       // the seed index answers captures with at most two 'N's when every reference is plain
       const bool seeded = G.seed_nb && bx == 0u && G.n_odd == 0u && __popc(bn) <= 2;
-      const uint32_t r = seeded ? wave_fix_error_seeded(G, b1, b2, bn) : wave_fix_error(G, b1, b2, bn, bx, true);
+      const uint32_t r = seeded ? wave_fix_error_seeded(G, b1, b2, bn, ((probed >> src) & 1ull) != 0ull)
+                                : wave_fix_error(G, b1, b2, bn, bx, true);
       if (lane == (uint32_t)src) out = r;
     }
     return out;
@@ -583,6 +775,7 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
     for (uint32_t i = tid; i < lhash_vec; i += kTPB) area[i] = image[i];
     ops.area = area;
     ops.with_tables = lhash_vec != 0u;
+    ops.abl_ = pl.abl();
   }
   // flags bit 2: the workgroup's hot-counter cache sits between the tables and the tiles
   const bool hot = (flags & 4u) != 0u;

@@ -867,40 +867,55 @@ BC_HD uint32_t single_n_lhash(const Quad* __restrict__ area, uint32_t off, uint3
 // the N-free capture (q1, q2) sits in one of its two buckets, so a lane that finds one there knows the
 // minimum distance (0 or 1) and how many references have it.  settled = false: nothing that near --
 // the pigeonhole search over all budget+1 blocks has to decide.
-BC_HD void tier_probe(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t& best, uint32_t& cnt, uint32_t& idx) {
-  const uint32_t blen = G.tier_blen, bm = (1u << blen) - 1u, nbk = 1u << (2u * blen);
-  const BC_GLOBAL uint32_t* bkt = G.tier_bkt();
-  // both buckets' heads (one line each) are requested before either is looked at: one round trip
+struct TierLines {
   uint32_t val[2];
-  uint32_t e[2][4][4];  // [block][entry]{r1, r2, index, references in the bucket}
+  Quad v[2][4];  // the two buckets' heads as loaded (the compact form fills two quads of each)
+};
+// both buckets' heads (one line each) are requested before either is looked at: one round trip.  Whole quads with
+// fixed positions: a per-dword loop over a length only known at run time ends up in scratch memory.
+BC_HD void tier_fetch(const DevGroup& G, uint32_t q1, uint32_t q2, TierLines& t) {
+  const uint32_t blen = G.tier_blen, bm = (1u << blen) - 1u, nbk = 1u << (2u * blen);
+  const BC_GLOBAL Quad* bkt = reinterpret_cast<const BC_GLOBAL Quad*>(G.tier_bkt());
 #pragma unroll
   for (uint32_t b = 0; b < 2; ++b) {
     const uint32_t sh = b * G.tier_stride;
-    val[b] = ((q1 >> sh) & bm) | (((q2 >> sh) & bm) << blen);
+    t.val[b] = ((q1 >> sh) & bm) | (((q2 >> sh) & bm) << blen);
     if (G.tier_compact) {
-      // 32 bytes: four entries of r1 | r2 << len | index << 2 len, the count in the first one's top three bits
-      const BC_GLOBAL uint32_t* line = bkt + ((size_t)b * nbk + val[b]) * 8u;
-      uint32_t w[8];
-#pragma unroll
-      for (uint32_t c = 0; c < 8; ++c) w[c] = line[c];
-      const uint32_t len = G.len, lm = lowmask(len);
-#pragma unroll
-      for (uint32_t k = 0; k < 4; ++k) {
-        const uint64_t x = ((uint64_t)w[2 * k + 1] << 32) | w[2 * k];
-        e[b][k][0] = (uint32_t)x & lm;
-        e[b][k][1] = (uint32_t)(x >> len) & lm;
-        e[b][k][2] = (uint32_t)((x & 0x1FFFFFFFFFFFFFFFull) >> (2u * len));
-        e[b][k][3] = 0;
-      }
-      e[b][0][3] = w[1] >> 29;
+      const BC_GLOBAL Quad* line = bkt + ((size_t)b * nbk + t.val[b]) * 2u;
+      t.v[b][0] = line[0];
+      t.v[b][1] = line[1];
     } else {
-      const BC_GLOBAL uint32_t* line = bkt + ((size_t)b * nbk + val[b]) * 16u;
-#pragma unroll
-      for (uint32_t k = 0; k < 4; ++k)
-#pragma unroll
-        for (uint32_t c = 0; c < 4; ++c) e[b][k][c] = line[k * 4u + c];
+      const BC_GLOBAL Quad* line = bkt + ((size_t)b * nbk + t.val[b]) * 4u;
+      t.v[b][0] = line[0];
+      t.v[b][1] = line[1];
+      t.v[b][2] = line[2];
+      t.v[b][3] = line[3];
     }
   }
+}
+// one entry of a bucket head: {r1, r2, index}; n = references in the bucket (valid for entry 0)
+template <uint32_t k>
+BC_HD void tier_entry(const DevGroup& G, const Quad* v, uint32_t& r1, uint32_t& r2, uint32_t& j, uint32_t& n) {
+  if (G.tier_compact) {
+    // 32 bytes: four entries of r1 | r2 << len | index << 2 len, the count in the first one's top three bits
+    const uint32_t len = G.len, lm = lowmask(len);
+    const Quad& h = v[k >> 1];
+    const uint32_t lo = (k & 1u) ? h.z : h.x, hi = (k & 1u) ? h.w : h.y;
+    const uint64_t x = ((uint64_t)hi << 32) | lo;
+    r1 = (uint32_t)x & lm;
+    r2 = (uint32_t)(x >> len) & lm;
+    j = (uint32_t)((x & 0x1FFFFFFFFFFFFFFFull) >> (2u * len));
+    n = hi >> 29;  // (capped at 7, which is all the callers' tests need)
+  } else {
+    r1 = v[k].x;
+    r2 = v[k].y;
+    j = v[k].z;
+    n = v[k].w;
+  }
+}
+BC_HD void tier_score(const DevGroup& G, uint32_t q1, uint32_t q2, const TierLines& t, uint32_t& best, uint32_t& cnt,
+                      uint32_t& idx) {
+  const uint32_t blen = G.tier_blen, bm = (1u << blen) - 1u, nbk = 1u << (2u * blen);
   best = 0xFFFFFFFFu;
   cnt = 0;
   idx = kFail;
@@ -919,16 +934,27 @@ BC_HD void tier_probe(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t& bes
   };
 #pragma unroll
   for (uint32_t b = 0; b < 2; ++b) {
-    const uint32_t n = e[b][0][3];  // (compact form: capped at 7, which is all the test below needs)
-#pragma unroll
-    for (uint32_t k = 0; k < 4; ++k) score(e[b][k][0], e[b][k][1], e[b][k][2], b == 1u, k < n);
+    uint32_t n, r1, r2, j, nk;
+    tier_entry<0>(G, t.v[b], r1, r2, j, n);
+    score(r1, r2, j, b == 1u, 0u < n);
+    tier_entry<1>(G, t.v[b], r1, r2, j, nk);
+    score(r1, r2, j, b == 1u, 1u < n);
+    tier_entry<2>(G, t.v[b], r1, r2, j, nk);
+    score(r1, r2, j, b == 1u, 2u < n);
+    tier_entry<3>(G, t.v[b], r1, r2, j, nk);
+    score(r1, r2, j, b == 1u, 3u < n);
     if (n > 4u) {  // the rest of a long bucket
       const BC_GLOBAL uint32_t* off = G.tier_off() + (size_t)b * (nbk + 1u);
       const BC_GLOBAL uint32_t* list = G.tier_list() + (size_t)b * G.n_idx * 4u;
-      for (uint32_t i = off[val[b]] + 4u, end = off[val[b] + 1u]; i < end; ++i)
+      for (uint32_t i = off[t.val[b]] + 4u, end = off[t.val[b] + 1u]; i < end; ++i)
         score(list[i * 4u], list[i * 4u + 1u], list[i * 4u + 2u], b == 1u, true);
     }
   }
+}
+BC_HD void tier_probe(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t& best, uint32_t& cnt, uint32_t& idx) {
+  TierLines t;
+  tier_fetch(G, q1, q2, t);
+  tier_score(G, q1, q2, t, best, cnt, idx);
 }
 
 BC_HD uint32_t tier_lookup(const DevGroup& G, uint32_t q1, uint32_t q2, bool& settled) {
@@ -972,8 +998,11 @@ struct ReadResult {
 // Ops must provide:
 //   bool any(bool)                               -- wave vote
 //   uint32_t nearest(const DevGroup&, q1,q2,qn,qx, bool need) -- cooperative Hamming search, every lane calls it
+//   uint32_t tier_single_n(const DevGroup&, q1,q2,qn, bool want, bool& settled) -- tier_lookup_single_n of the
+//                                                   lanes that want it, every lane calls it
 //   void sequence_consumed()                     -- called once, by every lane, after the last read of the
 //                                                   sequence bytes (the GPU starts fetching the next tile)
+//   void issued()                                -- loads written above this call are issued before anything below
 //   void mark(int)                               -- profiling hook (no-op outside BC_PROFILE builds)
 //   const Quad* lhash(), bool tables()           -- the LDS exact-match area (plan.lhash_vec uint4s), and whether
 //                                                   it is loaded
@@ -1145,40 +1174,53 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
               } else {
                 need_m |= 1u << u;
               }
-            } else if (G.mode == kSetHash) {
+            } else if (G.mode != kSetHash) {
               need_m |= 1u << u;
-              if (!clean && qx[u] == 0u && (qn[u] & (qn[u] - 1u)) == 0u && G.tier_blen && !(pl.abl() & 0x800u)) {
-                bool settled = false;
-                const uint32_t t = tier_lookup_single_n(G, q1[u], q2[u], qn[u], settled);
-                if (settled) {
-                  r[u] = t;
-                  need_m &= ~(1u << u);
-                }
+            }
+          }
+        }
+        if (G.mode == kSetHash) {  // wave-uniform: the lanes of the wave work together below
+          const bool clean = (qn[u] | qx[u]) == 0u;
+          const bool tier = G.tier_blen && !(pl.abl() & 0x800u);
+          const bool probe = located && clean;
+          const bool one_n = located && !clean && tier && qx[u] == 0u && (qn[u] & (qn[u] - 1u)) == 0u && !(pl.abl() & 0x4000u);
+          need_m |= located ? (1u << u) : 0u;
+          if (!clean && (pl.abl() & 0x4000u)) need_m &= ~(1u << u);  // experiment: captures with 'N' simply fail
+          if (tier) {
+            // the one-mismatch tier also finds the capture itself (distance 0): no separate exact lookup.  The
+            // plain captures' lines are requested first; the rare captures with one 'N' are then settled by the
+            // whole wave, their loads sharing the round trip
+            TierLines t;
+            if (probe) tier_fetch(G, q1[u], q2[u], t);
+            ops.issued();  // (the compiler would otherwise move the loads down to their use, behind the pass)
+            if (ops.any(one_n)) {
+              bool settled = false;
+              const uint32_t rn = ops.tier_single_n(G, q1[u], q2[u], qn[u], one_n, settled);
+              if (one_n && settled) {
+                r[u] = rn;
+                need_m &= ~(1u << u);
               }
-              if (clean && G.tier_blen && !(pl.abl() & 0x800u)) {
-                // the one-mismatch tier also finds the capture itself (distance 0): no separate exact lookup
-                bool settled = false;
-                const uint32_t t = tier_lookup(G, q1[u], q2[u], settled);
-                if (settled) {
-                  r[u] = t;
-                  need_m &= ~(1u << u);
-                }
-              } else if (clean) {
-                const uint64_t key = (uint64_t)q1[u] | ((uint64_t)q2[u] << 32);
-                uint32_t h = (uint32_t)hash64(key) & G.hmask;
-                for (;;) {
-                  const uint32_t v = G.hvals()[h];
-                  if (v == kFail) break;
-                  if (G.hkeys()[h] == key) {
-                    r[u] = v;
-                    need_m &= ~(1u << u);
-                    break;
-                  }
-                  h = (h + 1u) & G.hmask;
-                }
+            }
+            if (probe) {
+              uint32_t best, cnt, idx;
+              tier_score(G, q1[u], q2[u], t, best, cnt, idx);
+              if (best <= 1u) {
+                r[u] = (cnt == 1u && best <= G.max_err) ? idx : kFail;
+                need_m &= ~(1u << u);
               }
-            } else {
-              need_m |= 1u << u;
+            }
+          } else if (probe) {
+            const uint64_t key = (uint64_t)q1[u] | ((uint64_t)q2[u] << 32);
+            uint32_t h = (uint32_t)hash64(key) & G.hmask;
+            for (;;) {
+              const uint32_t v = G.hvals()[h];
+              if (v == kFail) break;
+              if (G.hkeys()[h] == key) {
+                r[u] = v;
+                need_m &= ~(1u << u);
+                break;
+              }
+              h = (h + 1u) & G.hmask;
             }
           }
         }
@@ -1272,6 +1314,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
           // a read that already failed an earlier group is not searched again (parse.rs:481, 500)
           bool nd_ = ((need_m >> u) & 1u) && outcome == kMatched;
           if (pl.abl() & 0x2u) nd_ = false;
+          if ((pl.abl() & 0x8000u) && qn[u]) nd_ = false;  // experiment: captures with 'N' never reach the search
           const uint32_t rr = ops.nearest(G, q1[u], q2[u], qn[u], qx[u], nd_);
           if (nd_) r[u] = rr;
           if (pre_ok && outcome == kMatched) {

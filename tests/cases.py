@@ -73,6 +73,13 @@ def build_case(name, seed=0, n=600):
         c["samples"] = None
         c["counted"] = [readgen.make_set(rng, 600, 16, 2)]
         c["reads"] = readgen.gen_reads(rng, c["scheme"], n, 100, None, c["counted"], p_sub=0.04, p_n=0.003)
+    elif name == "large_set_many_n":
+        # 20-nt guides, budget 4 (tier + coarse + full seed index): one capture in two holds an 'N', many hold two to
+        # five -- the substitution passes of the wave-cooperative search (bc_kernel.h tier_single_n / nearest)
+        c["scheme"] = CRISPR_SCHEME
+        c["samples"] = None
+        c["counted"] = [readgen.make_set(rng, 700, 20, 2)]
+        c["reads"] = readgen.gen_reads(rng, CRISPR_SCHEME, n, 100, None, c["counted"], p_sub=0.04, p_n=0.04)
     elif name == "fmtn":
         # scheme with N positions: [AGCT] in the regex, wildcard in repair, regions_string shift (Q9)
         c["scheme"] = FMTN_SCHEME
@@ -152,7 +159,7 @@ def build_case(name, seed=0, n=600):
 
 
 ALL_CASES = ["del_exact", "del_mismatch_quality", "del_dense_ties", "del_random", "example_files",
-             "example_files_samples", "crispr", "large_set_ties", "fmtn", "nosample_with_sample_file", "nosample",
+             "example_files_samples", "crispr", "large_set_ties", "large_set_many_n", "fmtn", "nosample_with_sample_file", "nosample",
              "refs_with_n_and_ragged", "other_chars", "long_gaps", "example_files_random_nosample", "raw_counted",
              "raw_sample", "raw_all_random"]
 

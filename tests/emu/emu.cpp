@@ -22,7 +22,12 @@ struct HostOps {
   const uint32_t* stage_quality(uint32_t) const { return qual32; }
   void sequence_consumed() const {}
   void mark(int) const {}
+  void issued() const {}
   bool any(bool c) const { return c; }
+  uint32_t tier_single_n(const bc::DevGroup& G, uint32_t q1, uint32_t q2, uint32_t qn, bool want, bool& settled) const {
+    settled = false;
+    return want ? bc::tier_lookup_single_n(G, q1, q2, qn, settled) : bc::kFail;
+  }
   uint32_t nearest(const bc::DevGroup& G, uint32_t q1, uint32_t q2, uint32_t qn, uint32_t qx, bool need) const {
     if (!need) return bc::kFail;
     bc::Nearest s;
