@@ -23,6 +23,14 @@ constexpr int kTPB = BC_TPB;       // reads (lanes) per workgroup
 // ------------------------------------------------------------------------------------------------
 // wave-level pieces
 // ------------------------------------------------------------------------------------------------
+// The lane's number, computed where it is asked for: the searches below run for a few reads in a hundred, and what
+// they derive from a lane number that is known once and for all (segment, entry, block ...) is otherwise hoisted out of
+// the loop over the tiles and kept in registers the hot path is short of.
+__device__ __forceinline__ uint32_t lane_now() {
+  uint32_t l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -48,7 +56,7 @@ __device__ __forceinline__ uint32_t wave_verdict(const Nearest& s, uint32_t max_
 // use_exact: a reference that IS the capture wins outright (AHashSet::contains, parse.rs:457/489).
 __device__ __forceinline__ uint32_t wave_fix_error(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t qn, uint32_t qx,
                                                    bool use_exact) {
-  const uint32_t lane = __lane_id();
+  const uint32_t lane = lane_now();
   Nearest s;
   nearest_init(s);
   for (uint32_t j = lane; j < G.n_refs; j += 64) {
@@ -74,7 +82,7 @@ __device__ __forceinline__ bool wave_scan_blocks(uint32_t nb, uint32_t blen, con
                                                  Nearest& s) {
   const uint32_t bm = (1u << blen) - 1u;
   const uint32_t nbk = 1u << (2 * blen);
-  const uint32_t lane = __lane_id();
+  const uint32_t lane = lane_now();
   const BC_GLOBAL uint4* entries = reinterpret_cast<const BC_GLOBAL uint4*>(list_base);
   for (uint32_t b = 0; b < nb; ++b) {
     const uint32_t val = ((q1 >> (b * blen)) & bm) | (((q2 >> (b * blen)) & bm) << blen);
@@ -117,7 +125,7 @@ __device__ __forceinline__ bool wave_scan_blocks_wide(uint32_t nb, uint32_t blen
                                                       uint32_t q2, Nearest& s) {
   const uint32_t bm = (1u << blen) - 1u;
   const uint32_t nbk = 1u << (2 * blen);
-  const uint32_t lane = __lane_id();
+  const uint32_t lane = lane_now();
   const BC_GLOBAL uint4* entries = reinterpret_cast<const BC_GLOBAL uint4*>(list_base);
   uint32_t beg[kMaxBlocks], end[kMaxBlocks];
 #pragma unroll
@@ -160,7 +168,7 @@ __device__ __forceinline__ bool wave_scan_blocks_wide(uint32_t nb, uint32_t blen
 // coarse_done: the coarse index has been asked already (coarse_probe_x4) and could not decide
 __device__ __forceinline__ void wave_seeded_min(const DevGroup& G, uint32_t q1, uint32_t q2, bool coarse_done, uint32_t& kmin_out,
                                                 bool& unique_out, uint32_t& idx_out) {
-  const uint32_t lane = __lane_id();
+  const uint32_t lane = lane_now();
   Nearest s;
   nearest_init(s);
   // the coarse index decides whenever some reference is within two mismatches (its three long blocks
@@ -212,7 +220,7 @@ __device__ __forceinline__ void coarse_probe_x4(const DevGroup& G, uint32_t q1, 
   const uint32_t nb = G.seed2_nb, blen = G.seed2_blen, n_idx = G.n_idx;
   const uint32_t bm = (1u << blen) - 1u;
   const uint32_t nbk = 1u << (2 * blen);
-  const uint32_t lane = __lane_id(), j = lane & 15u;
+  const uint32_t lane = lane_now(), j = lane & 15u;
   const BC_GLOBAL uint4* entries = reinterpret_cast<const BC_GLOBAL uint4*>(G.seed2_list());
   Nearest s;
   nearest_init(s);
@@ -518,6 +526,7 @@ struct DeviceOps {
   // of half the wave instead of four of all of it.  Every lane calls this.
   __device__ __forceinline__ uint32_t tier_single_n(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t qn, bool want,
                                                     bool& settled) const {
+    const uint32_t lane = lane_now();  // (not the member: see lane_now)
     uint32_t out = kFail;
     settled = false;
     unsigned long long todo = __ballot(want);
@@ -545,6 +554,7 @@ struct DeviceOps {
       if (G.tier_compact) {
         const BC_GLOBAL uint32_t* line = bkt + ((size_t)blk * nbk + val) * 8u;
         const uint2 wv = *reinterpret_cast<const BC_GLOBAL uint2*>(line + 2u * ent);  // one load, not one per word
+        asm volatile("" ::: "memory");  // (or the compiler fetches the second word in a round trip of its own, where it is used)
         const uint32_t w0 = wv.x, w1 = wv.y;
         const uint32_t len = G.len, lm = lowmask(len);
         const uint64_t x = ((uint64_t)w1 << 32) | w0;
@@ -554,6 +564,7 @@ struct DeviceOps {
         n_here = w1 >> 29;
       } else {
         const uint4 e = *reinterpret_cast<const BC_GLOBAL uint4*>(bkt + ((size_t)blk * nbk + val) * 16u + 4u * ent);
+        asm volatile("" ::: "memory");
         r1 = e.x;
         r2 = e.y;
         j = e.z;
@@ -577,6 +588,7 @@ struct DeviceOps {
         while (__any(i < end)) {
           if (i < end) {
             const uint4 le = *reinterpret_cast<const BC_GLOBAL uint4*>(list + (size_t)i * 4u);
+            asm volatile("" ::: "memory");
             const uint32_t l1 = le.x, l2 = le.y, lj = le.z;
             const uint32_t df = (c1 ^ l1) | (c2 ^ l2);
             if (!(blk == 1u && (df & bm) == 0u)) {
@@ -624,6 +636,7 @@ struct DeviceOps {
   // every lane calls this; lanes with `need` get their capture resolved one after the other
   __device__ __forceinline__ uint32_t nearest(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t qn, uint32_t qx,
                                               bool need) const {
+    const uint32_t lane = lane_now();  // (not the member: see lane_now)
     uint32_t out = kFail;
     unsigned long long todo = __ballot(need);
     unsigned long long probed = 0;  // captures the coarse index has been asked about
