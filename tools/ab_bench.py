@@ -25,6 +25,9 @@ ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--fresh", action="store_true", help="reset the engine before every launch: every matched read is a first occurrence")
 ap.add_argument("libs", nargs="+")
 args = ap.parse_args()
+zipf = args.config == "config5z"  # config 5 with Zipf-like guide abundances
+if zipf:
+    args.config = "config5"
 n = args.reads or {"config2": 10_000_000, "config3": 100_000_000, "config4": 50_000_000, "config5": 125_000_000}[args.config]
 dev = torch.device("cuda", 0)
 variants = []
@@ -41,7 +44,7 @@ for spec in args.libs:
     os.environ["BC_JIT_CACHE"] = os.path.join(ROOT, "gpurun_out", "ab", "cache_" + name.replace(":", "_"))
     os.makedirs(os.environ["BC_JIT_CACHE"], exist_ok=True)
     lib = _lib.load(os.path.abspath(path))
-    w = workloads.make(args.config, lib=lib, n_molecules=n // 2 if args.config == "config4" else None)
+    w = workloads.make(args.config, lib=lib, n_molecules=n // 2 if args.config == "config4" else None, zipf=zipf)
     R = w.read_len
     if table is None:
         table = torch.zeros(max(w.plan.table_entries, 1), dtype=torch.int32, device=dev)
