@@ -873,11 +873,12 @@ struct TierLines {
 };
 // both buckets' heads (one line each) are requested before either is looked at: one round trip.  Whole quads with
 // fixed positions: a per-dword loop over a length only known at run time ends up in scratch memory.
-BC_HD void tier_fetch(const DevGroup& G, uint32_t q1, uint32_t q2, TierLines& t) {
+template <uint32_t kFirst, uint32_t kLast>
+BC_HD void tier_fetch_blocks(const DevGroup& G, uint32_t q1, uint32_t q2, TierLines& t) {
   const uint32_t blen = G.tier_blen, bm = (1u << blen) - 1u, nbk = 1u << (2u * blen);
   const BC_GLOBAL Quad* bkt = reinterpret_cast<const BC_GLOBAL Quad*>(G.tier_bkt());
 #pragma unroll
-  for (uint32_t b = 0; b < 2; ++b) {
+  for (uint32_t b = kFirst; b <= kLast; ++b) {
     const uint32_t sh = b * G.tier_stride;
     t.val[b] = ((q1 >> sh) & bm) | (((q2 >> sh) & bm) << blen);
     if (G.tier_compact) {
@@ -893,6 +894,7 @@ BC_HD void tier_fetch(const DevGroup& G, uint32_t q1, uint32_t q2, TierLines& t)
     }
   }
 }
+BC_HD void tier_fetch(const DevGroup& G, uint32_t q1, uint32_t q2, TierLines& t) { tier_fetch_blocks<0, 1>(G, q1, q2, t); }
 // one entry of a bucket head: {r1, r2, index}; n = references in the bucket (valid for entry 0)
 template <uint32_t k>
 BC_HD void tier_entry(const DevGroup& G, const Quad* v, uint32_t& r1, uint32_t& r2, uint32_t& j, uint32_t& n) {
@@ -950,6 +952,34 @@ BC_HD void tier_score(const DevGroup& G, uint32_t q1, uint32_t q2, const TierLin
         score(list[i * 4u], list[i * 4u + 1u], list[i * 4u + 2u], b == 1u, true);
     }
   }
+}
+// The capture itself among the (at most four) references of its block-0 bucket: a reference at distance 0 is the
+// unique nearest one, whatever the other block's bucket holds.  False for a longer bucket or a reference listed twice:
+// tier_score decides those.
+BC_HD bool tier_exact_in_block0(const DevGroup& G, uint32_t q1, uint32_t q2, const TierLines& t, uint32_t& idx) {
+  uint32_t n, r1, r2, j, nk, hits = 0;
+  idx = kFail;
+  tier_entry<0>(G, t.v[0], r1, r2, j, n);
+  if (0u < n && ((q1 ^ r1) | (q2 ^ r2)) == 0u) {
+    ++hits;
+    idx = j;
+  }
+  tier_entry<1>(G, t.v[0], r1, r2, j, nk);
+  if (1u < n && ((q1 ^ r1) | (q2 ^ r2)) == 0u) {
+    ++hits;
+    idx = j;
+  }
+  tier_entry<2>(G, t.v[0], r1, r2, j, nk);
+  if (2u < n && ((q1 ^ r1) | (q2 ^ r2)) == 0u) {
+    ++hits;
+    idx = j;
+  }
+  tier_entry<3>(G, t.v[0], r1, r2, j, nk);
+  if (3u < n && ((q1 ^ r1) | (q2 ^ r2)) == 0u) {
+    ++hits;
+    idx = j;
+  }
+  return hits == 1u && n <= 4u;
 }
 BC_HD void tier_probe(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t& best, uint32_t& cnt, uint32_t& idx) {
   TierLines t;
@@ -1189,9 +1219,15 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
           if (tier) {
             // the one-mismatch tier also finds the capture itself (distance 0): no separate exact lookup.  The
             // plain captures' lines are requested first; the rare captures with one 'N' are then settled by the
-            // whole wave, their loads sharing the round trip
+            // whole wave, their loads sharing the round trip (moving the pass behind the second fetch: no gain)
             TierLines t;
+#ifdef BC_TIER_BOTH
             if (probe) tier_fetch(G, q1[u], q2[u], t);
+#else
+            // block 0's line first: four reads in five carry a reference unchanged, which that line alone proves --
+            // the other half of the tier is then touched by one read in five only and leaves the L2 to the first
+            if (probe) tier_fetch_blocks<0, 0>(G, q1[u], q2[u], t);
+#endif
             ops.issued();  // (the compiler would otherwise move the loads down to their use, behind the pass)
             if (ops.any(one_n)) {
               bool settled = false;
@@ -1201,7 +1237,18 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
                 need_m &= ~(1u << u);
               }
             }
-            if (probe) {
+#ifdef BC_TIER_BOTH
+            const bool exact = false;
+#else
+            uint32_t exact_idx = kFail;
+            const bool exact = probe && tier_exact_in_block0(G, q1[u], q2[u], t, exact_idx);
+            if (exact) {
+              r[u] = exact_idx;
+              need_m &= ~(1u << u);
+            }
+            if (probe && !exact) tier_fetch_blocks<1, 1>(G, q1[u], q2[u], t);
+#endif
+            if (probe && !exact) {
               uint32_t best, cnt, idx;
               tier_score(G, q1[u], q2[u], t, best, cnt, idx);
               if (best <= 1u) {
