@@ -372,10 +372,13 @@ __device__ __forceinline__ void table_add(uint32_t* p) {
 // (~60 M/s: a Zipf-like guide distribution ran 13 x slower than a uniform one).  Every workgroup therefore keeps
 // kHotSlots counters in LDS, claimed first come first served by the table indices it meets (tag = index, never
 // evicted): an abundant index is all but certain to claim its slot within the workgroup's first few hundred reads, and
-// from then on costs an LDS add; everything else goes to the table as before.  The slot of an index is a hash seeded
-// by the workgroup, so two abundant indices that collide in one workgroup do not in the others.  The cached counts are
+// from then on costs an LDS add; everything else goes to the table as before.  An index has two slots to try (two
+// hashes seeded by the workgroup), so two abundant indices that collide in one workgroup do not in the others.  The cached counts are
 // added to the table once, when the workgroup ends.  Plans whose table index fits 32 bits.
-constexpr uint32_t kHotBits = 8, kHotSlots = 1u << kHotBits, kHotEmpty = 0xFFFFFFFFu;
+#ifndef BC_HOT_BITS
+#define BC_HOT_BITS 8
+#endif
+constexpr uint32_t kHotBits = BC_HOT_BITS, kHotSlots = 1u << kHotBits, kHotEmpty = 0xFFFFFFFFu;
 constexpr uint32_t kHotBytes = kHotSlots * 8u;
 
 // ---- device hash set of 64-bit keys (the AHashSet<String> per tuple of info.rs:663, flattened) ----
@@ -937,8 +940,17 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
       if (hot && !pl.sparse && __any(add)) {
         // the workgroup's LDS counters first: an index that owns (or can still claim) its slot is counted there
         const uint32_t key = (uint32_t)r.dense_idx;
-        const uint32_t h = ((key ^ hot_seed) * 0x9E3779B1u) >> (32u - kHotBits);
+        uint32_t h = ((key ^ hot_seed) * 0x9E3779B1u) >> (32u - kHotBits);
         uint32_t tag = add ? hot_tag[h] : key ^ 1u;
+#ifndef BC_HOT_ONE
+        // taken by another index: a second slot to try.  With one slot per index the guides of rank ~20-250 of a
+        // Zipf-like library owned theirs in some workgroups only (whoever comes first keeps a slot), and what was
+        // left of their adds -- one address, ~60 M/s -- decided the kernel's time: 6.84 -> 5.75 ms per 125 M reads
+        if (add && tag != key && tag != kHotEmpty) {
+          h = ((key ^ hot_seed) * 0xC2B2AE35u) >> (32u - kHotBits);
+          tag = hot_tag[h];
+        }
+#endif
         if (add && tag == kHotEmpty) {
           const uint32_t old = atomicCAS(&hot_tag[h], kHotEmpty, key);
           tag = old == kHotEmpty ? key : old;
