@@ -14,11 +14,12 @@ tables are sum-reduced ONCE with RCCL inside the timed region, as the job would 
 Under torchrun (WORLD_SIZE set) this process is one rank; started plainly with --gpus N > 1 it
 starts the N ranks itself as child processes -- before anything here has touched a GPU -- and
 passes rank 0's line through.
-Prints ONE JSON line on rank 0.  Besides the contract's fields: `roofline` (dominant kernel, HIP events
-on the engine's stream), `cpu_baseline`, `end_to_end` (host buffers -> counts over PCIe), `reset_ms` /
-`finish_ms` (zeroing the 16 GB table; compacting it into sparse rows on the host), `box` (this box's own
-copy and random-atomic rates: boxes of the pool differ) and, at N = 1, `extra`: the other BASELINE
-configs in the same invocation, each with its own roofline.
+Prints ONE JSON line on rank 0 (stdout), as soon as the timed region, the box's copy rate and the CPU baseline are done:
+the contract's fields, `roofline` (dominant kernel, HIP events on the engine's stream; per-launch first / median / last),
+`cpu_baseline`, `box`, `reset_ms`.  Only then, at N = 1, the legs beside the headline run, each on its own and with its
+failure recorded instead of raised: `finish` (table -> sparse rows on the host), `end_to_end` (host buffers -> counts
+over PCIe), `ingest` (FASTQ file -> counts) and `extra` (the other BASELINE configs, each with its own roofline).  They
+go to stderr as one `BENCH_EXTRA {...}` line and to gpurun_out/bench_extra.json -- never to stdout.
 """
 import argparse
 import json
@@ -52,9 +53,10 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="config3", choices=sorted(DEFAULT_READS))
     ap.add_argument("--reads", type=int, default=0, help="reads per step per GPU (default: the config's size)")
-    ap.add_argument("--cpu-sample", type=int, default=1_500_000)
+    ap.add_argument("--cpu-sample", type=int, default=4_000_000,
+                    help="reads of the CPU baseline's independent-context leg (the reference-structure leg takes the first 1.5 M)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the other configs and the end-to-end / finish legs")
+    ap.add_argument("--no-extra", action="store_true", help="skip the legs beside the headline (finish, end-to-end, ingest, the other configs)")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="TEST ONLY (tests/test_bench_launcher.py): the rank plumbing on gloo with the host emulation of "
                          "the lane code; prints a line marked invalid, measures nothing")
@@ -197,126 +199,165 @@ def selftest_cpu(args, world, rank):
 # ------------------------------------------------------------------------------------------------
 # one workload on this rank's GPU
 # ------------------------------------------------------------------------------------------------
-def run_config(name, n, steps, warmup, world, rank, local, dev, legs):
-    """Counts `steps` x n resident reads of BASELINE config `name`; returns a dict of measurements (rank 0: complete).
-    legs: also measure reset / finish / host-submit / cpu baseline (rank 0, N = 1 reporting only)."""
-    import torch
-    import torch.distributed as dist
-    import ngs_barcode_count_amd as pkg
-    from ngs_barcode_count_amd import distributed as bcdist
-    import workloads
+class Run:
+    """One BASELINE config on this rank's GPU: resident batches, an engine, the timed steps.  measure() returns the
+    contract's numbers (rank 0: complete); the legs that are NOT part of the headline (finish, box ceilings, host
+    submit, ingest) are separate methods that main() calls only after the contract line is out."""
 
-    if name == "config5z":
-        w = workloads.make("config5", zipf=True)
-    elif name == "config4":
-        # PCR copies per molecule geometric with mean 2, scattered over one job = one step's reads of all ranks (the key
-        # set is cleared every step; every step draws the same molecules again with fresh sequencing errors)
-        w = workloads.make(name, geo_total=n * world)
-    else:
-        w = workloads.make(name)
-    R = w.read_len
-    with_qual = w.min_quality > 0
-    # N > 1: the counter table is this process's own tensor, so that it can be reduced with RCCL (allocated first: it is
-    # the randomly accessed one and should get the most contiguous device memory the process can have).  N = 1: the
-    # engine owns it, as in the command-line program.
-    table = torch.zeros(w.plan.table_entries, dtype=torch.int32, device=dev) if world > 1 else None
-    torch.cuda.synchronize()
-    # --- resident inputs: this rank's contiguous shard of the seeded read stream, one batch per step -----------------
-    # Every step counts reads it has not seen before (a job never counts the same batch twice), as many distinct
-    # batches as the HBM holds next to the table; with more steps than that the batches are gone through again.
-    batch_bytes = n * R * (2 if with_qual else 1)
-    free_b, _ = torch.cuda.mem_get_info(dev)
-    # (left free: the engine's table and bit map at N = 1; at N > 1 also the byte-packed slices of the table exchange)
-    spare = (24 << 30) if world == 1 else (48 << 30)
-    n_batches = int(max(1, min(steps, (free_b - spare) // batch_bytes)))
-    first_read, _ = bcdist.shard(n * n_batches * world, rank, world)
-    batches = []
-    for k in range(n_batches):
-        bs = torch.empty(n * R, dtype=torch.uint8, device=dev)
-        bq = torch.empty(n * R, dtype=torch.uint8, device=dev) if with_qual else None
-        w.synth.generate_device(local, None, first_read + k * n, n, bs.data_ptr(), bq.data_ptr() if with_qual else None)
-        batches.append((bs, bq))
-    torch.cuda.synchronize()
-    dseq, dqual = batches[0]
-    eng = pkg.Engine(w.plan, device=local, table_ptr=table.data_ptr() if table is not None else None)
-    random_mode = w.plan.random_barcode
-    step_no = [0]
-
-    def step():
-        if random_mode:
-            eng.clear_keys()  # a step is one whole job: otherwise every later step would see only duplicates
-        bs, bq = batches[step_no[0] % n_batches]
-        step_no[0] += 1
-        eng.submit_device(bs.data_ptr(), bq.data_ptr() if with_qual else None, n, R, R)
-
-    def barrier():
-        eng.sync()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-
-    for _ in range(warmup):
-        step()
-    if world > 1:
-        # warm-up of the end-of-job exchange too: RCCL sets up its peer-to-peer connections on first use
-        if random_mode:
-            bcdist.exchange_keys(torch.arange(world * 64, dtype=torch.int64, device=dev))
-        bcdist.reduce_table(torch.ones(world * 4096, dtype=torch.int32, device=dev), dst=0)
-    barrier()
-    t_r = time.perf_counter()
-    eng.reset()
-    eng.sync()
-    reset_ms = (time.perf_counter() - t_r) * 1e3
-    eng.timing(True)
-    step_no[0] = 0
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    eng.sync()  # (large dense tables: folds the first-occurrence bits into the table -- part of the job, inside the region)
-    t_steps = time.perf_counter() - t0
-    reduce_ms = 0.0
-    fixed_counters = None
-    if world > 1:
-        tr = time.perf_counter()
-        if random_mode:
-            # set sizes do not add: exchange the keys so that each has one owner (SURVEY.md 8(e)); every rank then
-            # turns its keys into per-tuple distinct counts and those tables are summed onto the root
-            fixed_counters = bcdist.finish_random(eng, dev, dst=0, table=table)
+    def __init__(self, name, n, steps, warmup, world, rank, local, dev):
+        import torch
+        import ngs_barcode_count_amd as pkg
+        from ngs_barcode_count_amd import distributed as bcdist
+        import workloads
+        self.torch, self.pkg, self.bcdist, self.workloads = torch, pkg, bcdist, workloads
+        self.name, self.n, self.steps, self.warmup = name, n, steps, warmup
+        self.world, self.rank, self.local, self.dev = world, rank, local, dev
+        if name == "config5z":
+            w = workloads.make("config5", zipf=True)
+        elif name == "config4":
+            # PCR copies per molecule geometric with mean 2, scattered over one job = one step's reads of all ranks (the
+            # key set is cleared every step; every step draws the same molecules again with fresh sequencing errors)
+            w = workloads.make(name, geo_total=n * world)
         else:
-            bcdist.reduce_table(table, dst=0)  # the job's one exchange: all-to-all sum of the counter tables
+            w = workloads.make(name)
+        self.w = w
+        self.R = R = w.read_len
+        self.with_qual = w.min_quality > 0
+        self.random_mode = w.plan.random_barcode
+        # The counters come first: the table is the randomly accessed allocation and gets the device memory of a fresh
+        # process; the resident batches then take what is left.  N > 1: the table is this process's own tensor, so that
+        # the job's end-of-run exchange can read it; N = 1: the engine owns it, as in the command-line program.
+        self.table = torch.zeros(w.plan.table_entries, dtype=torch.int32, device=dev) if world > 1 else None
         torch.cuda.synchronize()
-        reduce_ms = (time.perf_counter() - tr) * 1e3
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed, t_steps, reduce_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, t_steps, reduce_ms = t.tolist()
+        self.eng = pkg.Engine(w.plan, device=local, table_ptr=self.table.data_ptr() if self.table is not None else None)
+        # --- resident inputs: this rank's contiguous shard of the seeded read stream, one batch per step ------------
+        # Every step counts reads it has not seen before (a job never counts the same batch twice), as many distinct
+        # batches as the HBM holds next to the counters and the working memory of everything this process does later
+        # (finish staging, host-submit and ingest buffers; N > 1: the byte-packed slices of the table exchange).
+        batch_bytes = n * R * (2 if self.with_qual else 1)
+        free_b, _ = torch.cuda.mem_get_info(dev)
+        reserve = (6 << 30) if world == 1 else (6 << 30) + 3 * w.plan.table_entries
+        self.n_batches = int(max(1, min(steps, (free_b - reserve) // batch_bytes)))
+        first_read, _ = bcdist.shard(n * self.n_batches * world, rank, world)
+        self.first_read = first_read
+        self.batches = []
+        for k in range(self.n_batches):
+            bs = torch.empty(n * R, dtype=torch.uint8, device=dev)
+            bq = torch.empty(n * R, dtype=torch.uint8, device=dev) if self.with_qual else None
+            w.synth.generate_device(local, None, first_read + k * n, n, bs.data_ptr(), bq.data_ptr() if bq is not None else None)
+            self.batches.append((bs, bq))
+        torch.cuda.synchronize()
 
-    sclk = eng.sclk_mhz()  # straight after the timed steps: the clock the kernels actually ran at
-    kernel_ms, launches = eng.kernel_ms()
-    eng.timing(False)
-    counters = fixed_counters if fixed_counters is not None else bcdist.reduce_counters(eng.counters(), dev, dst=0)
-    total_reads = n * steps * world
-    res = None
-    if rank == 0:
+    def close(self):
+        self.eng.close()
+        self.batches = []
+        self.table = None
+        self.torch.cuda.empty_cache()
+
+    def _barrier(self):
+        self.eng.sync()
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.torch.distributed.barrier()
+
+    def measure(self):
+        torch, pkg, bcdist, eng, w = self.torch, self.pkg, self.bcdist, self.eng, self.w
+        dist = torch.distributed
+        n, R, steps, world, rank, dev = self.n, self.R, self.steps, self.world, self.rank, self.dev
+        step_no = [0]
+        carried = dict.fromkeys(pkg.COUNTER_NAMES, 0)  # outcome counters of the passes before a reset
+        resets = []
+
+        def step():
+            k = step_no[0] % self.n_batches
+            if self.random_mode:
+                eng.clear_keys()  # a step is one whole job: otherwise every later step would see only duplicates
+            elif k == 0 and step_no[0] > 0:
+                # every resident batch has been counted once: a job never counts a read twice, so the next pass over
+                # them is a new job -- counters read, table (and bit map) zeroed; inside the timed region, reported
+                t_r = time.perf_counter()
+                for key, v in eng.counters().items():
+                    carried[key] += v
+                eng.reset()
+                resets.append((time.perf_counter() - t_r) * 1e3)
+            bs, bq = self.batches[k]
+            step_no[0] += 1
+            eng.submit_device(bs.data_ptr(), bq.data_ptr() if bq is not None else None, n, R, R)
+
+        for _ in range(self.warmup):
+            step()
+        if world > 1:
+            # warm-up of the end-of-job exchange too: RCCL sets up its peer-to-peer connections on first use
+            if self.random_mode:
+                bcdist.exchange_keys(torch.arange(world * 64, dtype=torch.int64, device=dev))
+            bcdist.reduce_table(torch.ones(world * 4096, dtype=torch.int32, device=dev), dst=0)
+        self._barrier()
+        t_r = time.perf_counter()
+        eng.reset()
+        eng.sync()
+        reset_ms = (time.perf_counter() - t_r) * 1e3
+        eng.timing(True)
+        step_no[0] = 0
+        resets.clear()
+        for key in carried:
+            carried[key] = 0
+        self._barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        eng.sync()  # (a caller-owned table: folds the first-occurrence bits into it -- part of the job, inside the region)
+        t_steps = time.perf_counter() - t0
+        reduce_ms = 0.0
+        fixed_counters = None
+        if world > 1:
+            tr = time.perf_counter()
+            if self.random_mode:
+                # set sizes do not add: exchange the keys so that each has one owner (SURVEY.md 8(e)); every rank then
+                # turns its keys into per-tuple distinct counts and those tables are summed onto the root
+                fixed_counters = bcdist.finish_random(eng, dev, dst=0, table=self.table)
+            else:
+                bcdist.reduce_table(self.table, dst=0)  # the job's one exchange: all-to-all sum of the counter tables
+            torch.cuda.synchronize()
+            reduce_ms = (time.perf_counter() - tr) * 1e3
+        self._barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed, t_steps, reduce_ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed, t_steps, reduce_ms = t.tolist()
+
+        sclk = eng.sclk_mhz()  # straight after the timed steps: the clock the kernels actually ran at
+        each = eng.kernel_ms_each()
+        kernel_ms, launches = eng.kernel_ms()
+        eng.timing(False)
+        if fixed_counters is not None:
+            counters = fixed_counters
+        else:
+            local_counters = eng.counters()
+            for key in carried:
+                local_counters[key] += carried[key]
+            counters = bcdist.reduce_counters(local_counters, dev, dst=0)
+        if rank != 0:
+            return None
+        total_reads = n * steps * world
         six = sum(counters[k] for k in ("matched", "constant_region", "sample_barcode", "barcode", "duplicates", "low_quality"))
         # exactly one outcome per read (random-barcode mode clears its set every step, so it holds there too)
         assert six == total_reads == counters["total_reads"], counters
-        f_matched = (counters["matched"] + (counters["duplicates"] if random_mode else 0)) / max(counters["total_reads"], 1)
-        b_alg = workloads.bytes_per_read(w, f_matched)
+        f_matched = (counters["matched"] + (counters["duplicates"] if self.random_mode else 0)) / max(counters["total_reads"], 1)
+        b_alg = self.workloads.bytes_per_read(w, f_matched)
         avg_ms = kernel_ms / max(launches, 1)
         achieved = (b_alg * n) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        res = {"config": name, "workload": WORKLOAD_TEXT[name], "reads_per_step_per_gpu": n, "read_len": R,
-               "distinct_batches": n_batches,
-               "value": total_reads / elapsed, "ms_per_step": elapsed * 1e3 / steps, "reduce_ms": reduce_ms,
-               "reset_ms": reset_ms, "outcomes": {k: counters[k] for k in pkg.COUNTER_NAMES},
-               "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_launch": b_alg * n,
-                            "alg_bytes_per_read": b_alg, "kernel": eng.kernel_name(), "kernel_avg_ms": avg_ms,
-                            "launches": launches, "kernel_reads_per_s": n / (avg_ms * 1e-3) if avg_ms > 0 else 0.0,
-                            "sclk_mhz": sclk}}
+        srt = sorted(each) or [0.0]
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_launch": b_alg * n,
+                "alg_bytes_per_read": b_alg, "kernel": eng.kernel_name(), "kernel_avg_ms": avg_ms,
+                "launches": launches, "kernel_reads_per_s": n / (avg_ms * 1e-3) if avg_ms > 0 else 0.0,
+                # per launch, in step order: the table fills up as a job goes on (two-level counting: more second
+                # occurrences, each a table add on top of the bit), so first / median / last are stated, not one mean
+                "kernel_ms_first": each[0] if each else None, "kernel_ms_median": srt[len(srt) // 2],
+                "kernel_ms_last": each[-1] if each else None, "kernel_ms_min": srt[0], "kernel_ms_max": srt[-1],
+                "kernel_ms_each": [round(x, 4) for x in each[:64]],
+                "sclk_mhz": sclk}
         # HBM bytes per launch from the PMC counters (FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE),
         # measured in separate rocprofv3 passes of this very workload (tools/profile.sh) and committed
         # under profiles/; null when no summary of this config and size exists
@@ -325,53 +366,66 @@ def run_config(name, n, steps, warmup, world, rank, local, dev, legs):
             for f in reversed(prof):
                 js = json.load(open(os.path.join(ROOT, "profiles", f)))
                 wl = js.get("_workload", "")
-                if name in wl and "{:,}".format(n) in wl and "hbm_traffic_bytes_per_dispatch" in js:
-                    res["roofline"]["traffic"] = js["hbm_traffic_bytes_per_dispatch"]["total"]
-                    res["roofline"]["traffic_source"] = "profiles/" + f
+                if (self.name + ":") in wl and "{:,}".format(n) in wl and "hbm_traffic_bytes_per_dispatch" in js:
+                    roof["traffic"] = js["hbm_traffic_bytes_per_dispatch"]["total"]
+                    roof["traffic_source"] = "profiles/" + f
                     break
-        except OSError:
+        except (OSError, ValueError, KeyError):
             pass
+        res = {"config": self.name, "workload": WORKLOAD_TEXT[self.name], "reads_per_step_per_gpu": n, "read_len": R,
+               "distinct_batches": self.n_batches, "resets_in_region": len(resets), "reset_in_region_ms": sum(resets),
+               "value": total_reads / elapsed, "ms_per_step": elapsed * 1e3 / steps, "reduce_ms": reduce_ms,
+               "reset_ms": reset_ms, "outcomes": {k: counters[k] for k in pkg.COUNTER_NAMES}, "roofline": roof}
+        if not self.random_mode and world == 1 and w.plan.table_entries:
+            try:  # rows the table holds at the end of the region (since the last reset): one sweep of the table
+                res["table_rows_at_end"] = eng.nonzero_entries()
+                res["table_entries"] = w.plan.table_entries
+            except Exception as err:  # noqa: BLE001 -- a diagnostic never costs the measurement
+                res["table_rows_at_end"] = {"error": str(err)}
+        return res
 
-    if rank == 0 and legs:
-        # ---- the job's end: compaction of the table into sparse rows on the host (bc_engine_finish) ----
-        if not random_mode:
-            t_f = time.perf_counter()
-            n_rows = eng.finish()
-            res["finish_ms"] = (time.perf_counter() - t_f) * 1e3
-            res["finish_rows"] = n_rows
+    # ---- legs beside the headline (rank 0, N = 1), each called inside main()'s try/except ------------------------
+    def leg_finish(self):
+        """the job's end: compaction of the table into sparse rows on the host (bc_engine_finish: bounded staging)"""
+        t_f = time.perf_counter()
+        n_rows = self.eng.finish()
+        return {"finish_ms": (time.perf_counter() - t_f) * 1e3, "finish_rows": n_rows}
 
-        # ---- this box's own ceilings, measured after the timed region: boxes of the pool differ by up to ~20 % ----
+    def leg_box(self):
+        """this box's own ceilings: boxes of the pool differ by up to ~20 %"""
+        torch = self.torch
         box = {}
-        try:
-            src = dseq[: min(dseq.numel(), 2 << 30)]
-            dst = torch.empty_like(src)
+        dseq = self.batches[0][0]
+        src = dseq[: min(dseq.numel(), 2 << 30)]
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        for _ in range(5):
             dst.copy_(src)
-            torch.cuda.synchronize()
-            tc = time.perf_counter()
-            for _ in range(5):
-                dst.copy_(src)
-            torch.cuda.synchronize()
-            box["copy_GBps"] = 2.0 * src.numel() * 5 / (time.perf_counter() - tc) / 1e9
-            del dst
-        except RuntimeError:
-            pass
-        if w.plan.table_entries:
-            # random no-return atomics over the whole counter table (+1, then -1 at the same entries: the counts end as they
-            # were): the rate the memory system sustains for plain counting alone
-            box["atomic_Gps"] = pkg.probe_atomic_rate(local, eng.table_ptr, w.plan.table_entries, 1 << 27) / 1e9
-            box["atomic_table_bytes"] = w.plan.table_entries * 4
-        res["box"] = box
-        res["roofline"]["box_copy_GBps"] = box.get("copy_GBps")
-        res["roofline"]["frac_of_box_copy"] = (res["roofline"]["achieved"] / box["copy_GBps"]) if box.get("copy_GBps") else None
+        torch.cuda.synchronize()
+        box["copy_GBps"] = 2.0 * src.numel() * 5 / (time.perf_counter() - tc) / 1e9
+        del dst
+        if self.w.plan.table_entries and not self.random_mode:
+            # random no-return atomics over the whole counter table (+1, then -1 at the same entries: the counts end
+            # as they were): the rate the memory system sustains for plain counting alone
+            self.eng.sync()
+            box["atomic_Gps"] = self.pkg.probe_atomic_rate(self.local, self.eng.table_ptr, self.w.plan.table_entries, 1 << 27) / 1e9
+            box["atomic_table_bytes"] = self.w.plan.table_entries * 4
+        return box
 
-        # ---- end to end: host buffers -> counts (bc_engine_submit_host: pinned double buffers, H2D on a side stream) ----
-        m = min(n, 8_000_000)
-        hs = dseq[:m * R].cpu().numpy()
-        hq = dqual[:m * R].cpu().numpy() if with_qual else None
-        del batches[1:]
-        torch.cuda.empty_cache()
+    def host_sample(self, m):
+        dseq, dqual = self.batches[0]
+        hs = dseq[: m * self.R].cpu().numpy()
+        hq = dqual[: m * self.R].cpu().numpy() if self.with_qual else None
+        return hs, hq
+
+    def leg_end_to_end(self, hs, hq):
+        """host buffers -> counts (bc_engine_submit_host: pinned double buffers, H2D on a side stream)"""
+        eng, R = self.eng, self.R
+        m = hs.size // R
         eng.reset()
-        eng.submit_host(hs[: 1_000_000 * R], hq[: 1_000_000 * R] if with_qual else None, R, R)  # staging buffers allocated
+        eng.submit_host(hs[: 1_000_000 * R], hq[: 1_000_000 * R] if hq is not None else None, R, R)  # staging buffers allocated
         eng.sync()
         eng.reset()
         eng.sync()
@@ -379,24 +433,71 @@ def run_config(name, n, steps, warmup, world, rank, local, dev, legs):
         eng.submit_host(hs, hq, R, R)
         eng.sync()
         dt = time.perf_counter() - t_h
-        res["end_to_end"] = {"what": "bc_engine_submit_host: %d reads in pageable host arrays -> pinned staging -> H2D on a side "
-                                     "stream -> kernel, to the end of counting" % m,
-                             "value": m / dt, "unit": "reads/s", "pcie_GBps": m * R * (2 if with_qual else 1) / dt / 1e9}
         assert eng.counters()["total_reads"] == m
-        res["_host_sample"] = (hs, hq)
+        return {"what": "bc_engine_submit_host: %d reads in pageable host arrays -> pinned staging -> H2D on a side "
+                        "stream -> kernel, to the end of counting" % m,
+                "value": m / dt, "unit": "reads/s", "pcie_GBps": m * R * (2 if hq is not None else 1) / dt / 1e9}
 
-        # ---- ingest: a FASTQ file in the page cache -> counts (bc_fastq_count: parallel pread into pinned chunks, raw
-        # text over PCIe, newline scan / record split / gather on the device, match kernel) ----
-        try:
-            res["ingest"] = ingest_leg(eng, w, hs, hq, m, R)
-        except OSError as err:  # no room for the file
-            res["ingest"] = {"error": str(err)}
-    if rank != 0:
-        res = None
-    eng.close()
-    del table, dseq, dqual, batches
-    torch.cuda.empty_cache()
-    return res, w
+
+def cpu_baselines(w, sample, threads):
+    """The CPU oracle timed two ways on the host cores (baseline, not target): in the reference's own structure (the
+    contract's `value`), and with one independent context per thread -- no shared queue, no shared Results -- which is
+    the most the same per-read code gives on these cores."""
+    import threading
+    import numpy as np
+    import oracle_lib
+    R = w.read_len
+    m = min(sample, 1_500_000)
+    seq, qual = w.synth.generate_host(0, sample)
+    if w.min_quality <= 0:
+        qual = None
+    rate, done, _ = cpu_baseline(w, seq[: m * R], qual[: m * R] if qual is not None else None, threads)
+    out = {"value": rate, "unit": "reads/s", "cores": threads, "kind": "port",
+           "sample": "first %d reads of rank 0's shard; CPU oracle (C restatement of parse.rs) in the reference's "
+                     "structure: 1 reader + %d workers on a mutex-guarded deque, one mutex-guarded Results "
+                     "(main.rs:69-121)" % (done, threads - 1)}
+    try:
+        ctxs = [workloads_oracle(w) for _ in range(threads)]
+        n = seq.size // R
+        cuts = [n * i // threads for i in range(threads + 1)]
+
+        def work(i):
+            a, b = cuts[i], cuts[i + 1]
+            ctxs[i].process_batch(seq[a * R:b * R], qual[a * R:b * R] if qual is not None else None, R, R)
+
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        dt = time.perf_counter() - t0
+        assert sum(sum(c.counters.values()) for c in ctxs) == n
+        out["independent_contexts"] = {"value": n / dt, "unit": "reads/s", "cores": threads,
+                                       "sample": "first %d reads, one oracle context per thread on its own slice, no shared "
+                                                 "queue or Results (not the reference's structure)" % n}
+    except Exception as err:  # noqa: BLE001
+        out["independent_contexts"] = {"error": repr(err)}
+    return out
+
+
+def workloads_oracle(w):
+    import workloads
+    return workloads.oracle_for(w)
+
+
+def emit_extras(extras):
+    """what is measured beside the contract line goes to stderr and to gpurun_out/bench_extra.json: stdout carries ONE line"""
+    text = json.dumps(extras)
+    sys.stderr.write("BENCH_EXTRA " + text + "\n")
+    sys.stderr.flush()
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "bench_extra.json"), "w") as f:
+            f.write(text + "\n")
+    except OSError:
+        pass
 
 
 def main():
@@ -431,14 +532,14 @@ def main():
     dev = torch.device("cuda", local)
 
     n = args.reads or DEFAULT_READS[args.config]
-    legs = world == 1 and not args.no_extra
-    res, w = run_config(args.config, n, args.steps, args.warmup, world, rank, local, dev, legs)
+    run = Run(args.config, n, args.steps, args.warmup, world, rank, local, dev)
+    res = run.measure()
     if rank != 0:
+        run.close()
         if world > 1:
             dist.destroy_process_group()
         return
 
-    host_sample = res.pop("_host_sample", None)
     crispr = args.config.startswith("config5")
     out = {
         "metric": "reads/sec (whole node), CRISPR 20nt vs 100k guides" if crispr else "reads/sec (whole node), 3x8nt DEL vs 3x1k refs",
@@ -454,41 +555,80 @@ def main():
         "dtype": "u8",
         "data": "synthetic",
         "config": {"workload": res["workload"], "config": args.config, "reads_per_step_per_gpu": n, "read_len": res["read_len"],
-                   "distinct_batches": res["distinct_batches"],
+                   "distinct_batches": res["distinct_batches"], "resets_in_region": res["resets_in_region"],
                    "parallelism": "reads sharded over %d GPU(s); one all-to-all sum of the counter tables over xGMI at the end" % world},
         "roofline": res["roofline"],
         "outcomes": res["outcomes"],
         "reduce_ms": res["reduce_ms"],
         "reset_ms": res["reset_ms"],
+        "reset_in_region_ms": res["reset_in_region_ms"],
     }
-    for k in ("finish_ms", "finish_rows", "end_to_end", "ingest", "box"):
+    for k in ("table_rows_at_end", "table_entries"):
         if k in res:
             out[k] = res[k]
-
+    if world == 1:
+        try:  # this box's copy rate (5 copies of 2 GiB: 10 ms): the headline's second denominator
+            box = run.leg_box()
+            out["box"] = box
+            out["roofline"]["box_copy_GBps"] = box.get("copy_GBps")
+            out["roofline"]["frac_of_box_copy"] = out["roofline"]["achieved"] / box["copy_GBps"] if box.get("copy_GBps") else None
+        except Exception as err:  # noqa: BLE001 -- nothing beside the timed region may cost the line
+            out["box"] = {"error": repr(err)}
     if not args.no_cpu:
-        m = min(args.cpu_sample, n)
-        if host_sample is not None:
-            hs, hq = host_sample[0][: m * w.read_len], (host_sample[1][: m * w.read_len] if host_sample[1] is not None else None)
-        else:
-            synth_seq, synth_qual = w.synth.generate_host(0, m)
-            hs, hq = synth_seq, (synth_qual if w.min_quality > 0 else None)
-        threads = max(2, min(os.cpu_count() or 2, 16))
-        rate, done, _ = cpu_baseline(w, hs, hq, threads)
-        out["cpu_baseline"] = {"value": rate, "unit": "reads/s", "cores": threads, "kind": "port",
-                               "sample": "first %d reads of rank 0's batch; CPU oracle (C restatement of parse.rs) in the "
-                                         "reference's structure: 1 reader + %d workers on a mutex-guarded deque, one "
-                                         "mutex-guarded Results (main.rs:69-121)" % (done, threads - 1)}
-    del host_sample
-
-    if legs and args.config == "config3":
-        # the other BASELINE configs, each at its own size, a few steps each (the headline stays config 3)
-        extra = []
-        for name in ("config2", "config4", "config5", "config5z"):
-            r, _ = run_config(name, DEFAULT_READS[name], 3, 1, 1, 0, local, dev, False)
-            extra.append({k: r[k] for k in ("config", "workload", "reads_per_step_per_gpu", "distinct_batches", "value",
-                                            "ms_per_step", "roofline", "outcomes")})
-        out["extra"] = extra
+        try:
+            out["cpu_baseline"] = cpu_baselines(run.w, min(args.cpu_sample, n), max(2, min(os.cpu_count() or 2, 16)))
+        except Exception as err:  # noqa: BLE001
+            out["cpu_baseline"] = {"error": repr(err)}
+    # ---- the contract line: out before anything optional runs ---------------------------------------------------
     print(json.dumps(out))
+    sys.stdout.flush()
+
+    if world == 1 and not args.no_extra:
+        extras = {"of": {"config": args.config, "steps": args.steps, "warmup": args.warmup}}
+
+        def leg(name, fn):
+            t0 = time.perf_counter()
+            try:
+                extras[name] = fn()
+            except BaseException as err:  # noqa: BLE001 -- recorded, the next leg still runs
+                extras[name] = {"error": repr(err)}
+                if isinstance(err, KeyboardInterrupt):
+                    raise
+            sys.stderr.write("bench.py: leg %s done in %.1f s\n" % (name, time.perf_counter() - t0))
+
+        if not run.random_mode:
+            leg("finish", run.leg_finish)
+        sample = [None, None]
+
+        def e2e():
+            m = min(n, 8_000_000)
+            sample[0], sample[1] = run.host_sample(m)
+            del run.batches[1:]
+            torch.cuda.empty_cache()
+            return run.leg_end_to_end(sample[0], sample[1])
+
+        leg("end_to_end", e2e)
+        if sample[0] is not None:
+            leg("ingest", lambda: ingest_leg(run.eng, run.w, sample[0], sample[1], sample[0].size // run.R, run.R))
+        run.close()
+        del sample
+        if args.config == "config3":
+            # the other BASELINE configs, each at its own size, a few steps each (the headline stays config 3)
+            extras["extra"] = []
+            for name in ("config2", "config4", "config5", "config5z"):
+                def other(name=name):
+                    r2 = Run(name, DEFAULT_READS[name], 5, 2, 1, 0, local, dev)
+                    try:
+                        r = r2.measure()
+                    finally:
+                        r2.close()
+                    return {k: r[k] for k in ("config", "workload", "reads_per_step_per_gpu", "distinct_batches", "value",
+                                              "ms_per_step", "roofline", "outcomes")}
+                leg("_" + name, other)
+                extras["extra"].append(extras.pop("_" + name))
+        emit_extras(extras)
+    else:
+        run.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -138,17 +138,32 @@ int bc_engine_reset(bc_engine *e);
 
 /* SequenceErrors values (u64; the reference wraps at 2^32, info.rs:17-22) */
 int bc_engine_counters(bc_engine *e, uint64_t out[BC_NCOUNTERS]);
-/* device pointers, for cross-device reduction by the caller (RCCL sum over u32 / u64) */
+/* device pointers, for cross-device reduction by the caller (RCCL sum over u32 / u64).  The table holds plain u32
+ * counts when this returns and again after every later bc_engine_sync (large tables count on two levels in between,
+ * bc_kernel.h: taking the pointer makes every sync fold them, as for a caller-owned table). */
 void *bc_engine_table_ptr(bc_engine *e);
 void *bc_engine_counters_ptr(bc_engine *e);
 uint64_t bc_engine_table_entries(const bc_engine *e);
 
 /* Compacts the non-zero table entries on the device; rows are then readable in any order.
  * A row = (sample index, barcode index per counted barcode, count): the (sample, tuple, count)
- * triples Results holds (info.rs:661-665), with indices into the plan's known sets. */
+ * triples Results holds (info.rs:661-665), with indices into the plan's known sets.
+ * Device memory is bounded whatever the table holds: the table is compacted range by range through two staging
+ * buffers of BC_FINISH_CHUNK_ROWS rows (default 2^22; 12 bytes per row on the device and pinned).  bc_engine_finish
+ * keeps all rows on the host (12 bytes per row; BC_ERR_NOMEM when that does not fit). */
 int bc_engine_finish(bc_engine *e, uint64_t *n_rows);
 int bc_engine_rows(bc_engine *e, uint64_t first, uint64_t n, uint32_t *sample_idx, uint32_t *barcode_idx,
                    uint64_t *count);
+/* The same compaction with the rows handed to `fn` chunk by chunk as they leave the device (nothing is kept: host
+ * memory is bounded too).  A chunk is n (key, count) pairs valid during the call; key = the dense table index
+ * (bc_engine_decode_index turns it into set indices) or, for plans that keep raw captures, the tuple key.  fn returns 0
+ * to go on; anything else stops the compaction (BC_ERR_STATE). */
+typedef int (*bc_rows_fn)(const uint64_t *key, const uint32_t *count, uint64_t n, void *user);
+int bc_engine_finish_stream(bc_engine *e, bc_rows_fn fn, void *user, uint64_t *n_rows);
+int bc_engine_decode_index(const bc_engine *e, uint64_t dense_index, uint32_t *sample_idx, uint32_t *barcode_idx);
+/* number of rows bc_engine_finish would produce now (dense plans without a random barcode): one sweep of the table,
+ * nothing is moved */
+int bc_engine_nonzero_entries(bc_engine *e, uint64_t *n);
 
 /* Row i as the reference's Results holds it (info.rs:661-665): the sample key (a sample barcode
  * sequence, or "barcode" without a sample group) and the counted barcodes "b1,b2,.." as sequences.
@@ -201,7 +216,10 @@ int bc_engine_trace(bc_engine *e, void *d_outcome_u8, void *d_index_u64);
 
 /* HIP-event timing of the match/count kernel on the engine's stream (for the roofline) */
 int bc_engine_timing(bc_engine *e, int enable);
-int bc_engine_kernel_ms(bc_engine *e, double *total_ms, uint64_t *launches);
+int bc_engine_kernel_ms(bc_engine *e, double *total_ms, uint64_t *launches);   /* sum since the last call; resets */
+/* the same launches one by one, in launch order (up to `capacity` of them; *launches = how many there are); does not
+ * reset: call it before bc_engine_kernel_ms */
+int bc_engine_kernel_ms_each(bc_engine *e, double *ms_out, uint64_t capacity, uint64_t *launches);
 /* Which kernel the last submit launched: "match_count_kernel<NW,NWW>" (the generic one, any plan) or
  * "bc_jit_match_count<NW,NWW>" (the one specialised to this plan's scheme); "" before the first submit. */
 const char *bc_engine_kernel_name(bc_engine *e);
@@ -210,9 +228,11 @@ const char *bc_engine_kernel_name(bc_engine *e);
  * and thermal limits, and the match kernel's time follows it. */
 int bc_engine_sclk_mhz(bc_engine *e, double *mhz);
 
-/* Box diagnostic for benchmarks: issues ~n_atomics no-return atomic adds of ZERO (the table's contents stay what they
- * are) at random entries of a u32 table and reports the sustained rate -- what the memory system of THIS device gives
- * the match kernel's counting alone (it differs between boxes by tens of percent). */
+/* Box diagnostic for benchmarks: issues ~n_atomics no-return atomic adds of +1 at random entries of a u32 table, then
+ * the same adds of -1 at the same entries (the table ends as it was, but is transiently different: the caller must be
+ * idle on it), and reports the sustained rate of the first pass -- what the memory system of THIS device gives the match
+ * kernel's counting alone (it differs between boxes by tens of percent).  Runs on the NULL stream and waits for the
+ * device; it is not ordered against work on a non-blocking stream, so sync the engine first. */
 int bc_probe_atomic_rate(int device_id, void *d_table_u32, uint64_t entries, uint64_t n_atomics, double *atomics_per_s);
 
 /* Scheme-specialised kernels.  Next to the generic kernel (any plan, plan read from memory) an engine

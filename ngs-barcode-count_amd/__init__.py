@@ -236,6 +236,41 @@ class Engine:
         _check(self._lib, self._lib.bc_engine_kernel_ms(self._e, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def kernel_ms_each(self):
+        """per-launch times (ms) of the match kernel since the last kernel_ms(), in launch order"""
+        n = C.c_uint64()
+        _check(self._lib, self._lib.bc_engine_kernel_ms_each(self._e, None, 0, C.byref(n)))
+        out = (C.c_double * max(n.value, 1))()
+        _check(self._lib, self._lib.bc_engine_kernel_ms_each(self._e, out, n.value, C.byref(n)))
+        return [float(out[i]) for i in range(n.value)]
+
+    def nonzero_entries(self):
+        """rows finish() would produce now (dense plans, no random barcode): one sweep of the table"""
+        n = C.c_uint64()
+        _check(self._lib, self._lib.bc_engine_nonzero_entries(self._e, C.byref(n)))
+        return n.value
+
+    def finish_stream(self, on_rows):
+        """bc_engine_finish_stream: on_rows(keys uint64 array, counts uint32 array) per chunk (copies of the chunk);
+        returns the number of rows.  Host and device memory stay bounded whatever the table holds."""
+        err = []
+
+        def cb(kp, cp, n, _user):
+            try:
+                on_rows(np.ctypeslib.as_array(kp, shape=(n,)).copy(), np.ctypeslib.as_array(cp, shape=(n,)).copy())
+                return 0
+            except Exception as ex:  # never let an exception cross the C frames
+                err.append(ex)
+                return 1
+
+        fn = _lib.ROWS_FN(cb)
+        n = C.c_uint64()
+        rc = self._lib.bc_engine_finish_stream(self._e, fn, None, C.byref(n))
+        if err:
+            raise err[0]
+        _check(self._lib, rc)
+        return n.value
+
     def finish(self):
         """bc_engine_finish: compacts the results into sparse rows; returns their number"""
         n = C.c_uint64()

@@ -12,6 +12,9 @@ COUNTER_NAMES = ["matched", "constant_region", "sample_barcode", "barcode", "dup
                  "total_reads", "unsupported_reads"]
 
 
+ROWS_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_uint64, C.c_void_p)  # bc_rows_fn
+
+
 class SynthParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("read_len", C.c_uint32), ("p_sub", C.c_uint32), ("p_n", C.c_uint32),
                 ("p_lowq", C.c_uint32), ("phred_lo", C.c_uint8), ("phred_hi", C.c_uint8), ("lowq_lo", C.c_uint8),
@@ -73,8 +76,12 @@ ENGINE_API = {
     "bc_engine_table_entries": (_u64, [_vp]),
     "bc_engine_finish": (_int, [_vp, C.POINTER(C.c_uint64)]),
     "bc_engine_rows": (_int, [_vp, _u64, _u64, _vp, _vp, _vp]),
+    "bc_engine_finish_stream": (_int, [_vp, _vp, _vp, C.POINTER(C.c_uint64)]),
+    "bc_engine_nonzero_entries": (_int, [_vp, C.POINTER(C.c_uint64)]),
+    "bc_engine_decode_index": (_int, [_vp, _u64, C.POINTER(_u32), C.POINTER(_u32)]),
     "bc_engine_timing": (_int, [_vp, _int]),
     "bc_engine_kernel_ms": (_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "bc_engine_kernel_ms_each": (_int, [_vp, C.POINTER(C.c_double), _u64, C.POINTER(C.c_uint64)]),
     "bc_table_pack_u8": (_int, [_vp, _u64, _vp, _vp, _vp, _u64, C.POINTER(_u64), _int, _vp]),
     "bc_table_sum_u8": (_int, [_vp, _u32, _u64, _vp, _int, _vp]),
     "bc_engine_kernel_name": (_cp, [_vp]),
