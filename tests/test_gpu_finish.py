@@ -117,17 +117,14 @@ def test_finish_reports_out_of_memory_and_stays_usable(monkeypatch):
     from ngs_barcode_count_amd import _lib
     monkeypatch.setenv("BC_FINISH_CHUNK_ROWS", str(1 << 26))  # 2 x 768 MB of staging wanted (capped by the rows)
     w = workloads.make("config3", n_sets=(4, 300, 300, 300))
-    n = 2_000_000
+    n = 4_000_000
     eng = pkg.Engine(w.plan, device=0)
     _submit(w, eng, 0, n)
-    expect_rows = eng.nonzero_entries()
+    expect_rows = eng.nonzero_entries()  # ~3.5 M rows: one staging slot of ~42 MB
     torch.cuda.empty_cache()
     ballast = []
-    for piece in (1 << 30, 1 << 26, 1 << 22):
-        while True:
-            free_b, _ = torch.cuda.mem_get_info()
-            if free_b - piece < (4 << 20):
-                break
+    for piece in (1 << 30, 1 << 26, 1 << 22, 1 << 21):  # until the device really has nothing left (mem_get_info is
+        while True:                                      # only an estimate of what the next hipMalloc can get)
             try:
                 ballast.append(torch.empty(piece, dtype=torch.uint8, device="cuda"))
             except RuntimeError:

@@ -48,6 +48,28 @@ __global__ void scatter_add_policy(uint32_t* table, uint64_t range, uint32_t per
   }
 }
 
+// scope / return-value variants: kScope 0 = agent (what atomicAdd is), 1 = workgroup (the atomic may be done in the
+// XCD's own L2: only correct when no other XCD touches the address during the kernel); kRet: the old value is used
+template <int kScope, int kRet, int kOr>
+__global__ void scatter_scope(uint32_t* table, uint64_t range, uint32_t per, uint64_t seed, uint32_t* sink) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t acc = 0;
+  for (uint32_t i = 0; i < per; ++i) {
+    const uint64_t h = mix(seed + t * per + i);
+    uint32_t* p = &table[h % range];
+    uint32_t old;
+    if (kOr) {
+      old = kScope ? __hip_atomic_fetch_or(p, 1u << (h >> 59), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                   : __hip_atomic_fetch_or(p, 1u << (h >> 59), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      old = kScope ? __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                   : __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (kRet) acc += old;
+  }
+  if (kRet && acc == 0xFFFFFFFFu) sink[0] = acc;
+}
+
 // same address stream, plain loads (what a gather of that locality costs)
 __global__ void scatter_load(const uint32_t* table, uint64_t range, uint32_t per, uint64_t seed, uint32_t* sink) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -87,7 +109,7 @@ int main() {
   hipEventCreate(&e0); hipEventCreate(&e1);
   const uint32_t per = 16, threads = 256, blocks = 256 * 64;  // 67 M operations per launch
   const double n = (double)per * threads * blocks;
-  const uint64_t ranges[] = {1ull << 20, 1ull << 22, 1ull << 24, 1ull << 26, 1ull << 28, 1ull << 30, 4ull << 30};
+  const uint64_t ranges[] = {1ull << 18, 1ull << 20, 1ull << 22, 1ull << 24, 1ull << 26, 1ull << 27, 1ull << 28, 1ull << 30, 4ull << 30};
   for (uint64_t r : ranges) {
     float ms_a = 0, ms_l = 0;
     for (int rep = 0; rep < 3; ++rep) {
@@ -115,9 +137,26 @@ int main() {
         hipEventElapsedTime(&ms_p[pol], e0, e1);
       }
     }
+    float ms_s[6] = {0, 0, 0, 0, 0, 0};
+    for (int v = 0; v < 6; ++v) {
+      for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0);
+        if (v == 0) hipLaunchKernelGGL((scatter_scope<0, 0, 0>), dim3(blocks), dim3(threads), 0, 0, table, r, per, 555ull + rep, sink);
+        if (v == 1) hipLaunchKernelGGL((scatter_scope<1, 0, 0>), dim3(blocks), dim3(threads), 0, 0, table, r, per, 555ull + rep, sink);
+        if (v == 2) hipLaunchKernelGGL((scatter_scope<0, 1, 0>), dim3(blocks), dim3(threads), 0, 0, table, r, per, 555ull + rep, sink);
+        if (v == 3) hipLaunchKernelGGL((scatter_scope<1, 1, 0>), dim3(blocks), dim3(threads), 0, 0, table, r, per, 555ull + rep, sink);
+        if (v == 4) hipLaunchKernelGGL((scatter_scope<0, 1, 1>), dim3(blocks), dim3(threads), 0, 0, table, r, per, 555ull + rep, sink);
+        if (v == 5) hipLaunchKernelGGL((scatter_scope<1, 1, 1>), dim3(blocks), dim3(threads), 0, 0, table, r, per, 555ull + rep, sink);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms_s[v], e0, e1);
+      }
+    }
     printf("range %8.0f MiB  atomics %7.2f G/s   loads %7.2f G/s   asm: plain %6.2f  nt %6.2f  sc1 %6.2f  sc1+nt %6.2f G/s\n",
            r * 4.0 / (1 << 20), n / ms_a / 1e6, n / ms_l / 1e6, n / ms_p[0] / 1e6, n / ms_p[1] / 1e6, n / ms_p[2] / 1e6,
            n / ms_p[3] / 1e6);
+    printf("                     add agent %6.2f  add wg-scope %6.2f | returning: add agent %6.2f  add wg %6.2f  or agent %6.2f  or wg %6.2f G/s\n",
+           n / ms_s[0] / 1e6, n / ms_s[1] / 1e6, n / ms_s[2] / 1e6, n / ms_s[3] / 1e6, n / ms_s[4] / 1e6, n / ms_s[5] / 1e6);
     fflush(stdout);
   }
   for (uint32_t regions : {1u, 64u, 1024u, 16384u}) {
