@@ -81,6 +81,81 @@ def test_config4_random_barcode_vs_oracle():
     eng.close()
 
 
+def _oracle_outcomes_parallel(w, seq, qual, threads=12):
+    """per-read outcome codes and the merged rows of `threads` independent oracle contexts, one slice each (the
+    oracle's linear fix_error over 100 k guides takes ~2 ms per corrected read: a minute on one core)"""
+    import threading
+    from collections import Counter
+    R = w.read_len
+    n = seq.size // R
+    cuts = [n * i // threads for i in range(threads + 1)]
+    ctxs = [workloads.oracle_for(w) for _ in range(threads)]
+    outs = [None] * threads
+
+    def work(i):
+        a, b = cuts[i], cuts[i + 1]
+        outs[i] = ctxs[i].process_batch_outcomes(seq[a * R:b * R], qual[a * R:b * R] if qual is not None else None, R, R)
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    rows = Counter()
+    counters = Counter()
+    for c in ctxs:
+        for s_, t_, k in c.rows():
+            rows[(s_, t_)] += k
+        counters.update(c.counters)
+    return np.concatenate(outs), sorted((s_, t_, k) for (s_, t_), k in rows.items()), dict(counters)
+
+
+def test_config5_scale_errors_reach_every_search_tier():
+    """the 100 k-guide searches beyond one mismatch were only ever checked on a few hundred reads.  Here
+    9 % substitutions and 2 % N over the full library: nearly every read needs its constant region repaired, most
+    captures miss the exact tier, thousands go through the coarse and the full seed index, hundreds carry several
+    N -- every read's outcome against the oracle, then the rows"""
+    import torch
+    import ngs_barcode_count_amd as pkg
+    w = workloads.make("config5", synth_overrides=dict(p_sub=0.09, p_n=0.02))
+    n = 24_000
+    R = w.read_len
+    seq, qual = w.synth.generate_host(0, n)
+    d_out = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    d_idx = torch.zeros(n, dtype=torch.int64, device="cuda")
+    eng = pkg.Engine(w.plan, device=0)
+    eng.trace(d_out.data_ptr(), d_idx.data_ptr())
+    _run(w, 0, n, eng=eng, chunk=n)
+    exp_out, exp_rows, exp_counters = _oracle_outcomes_parallel(w, seq, None)
+    got_out = d_out.cpu().numpy()
+    bad = np.nonzero(got_out != exp_out)[0]
+    assert bad.size == 0, (bad[:5], got_out[bad[:5]], exp_out[bad[:5]],
+                           [bytes(seq[i * R:(i + 1) * R]).decode() for i in bad[:2]])
+    got = eng.counters()
+    assert {k: got[k] for k in exp_counters} == exp_counters
+    # the workload really exercises what it is meant to: failures of both kinds and plenty of corrected reads
+    assert got["barcode"] > 400 and got["constant_region"] > 100 and got["matched"] > n // 2
+    assert eng.result_rows() == exp_rows
+    eng.close()
+
+
+def test_config4_bench_variant_vs_oracle():
+    """config 4 as bench.py runs it: PCR copies per molecule geometric with mean 2, scattered over the job by a fixed
+    permutation (geo_total = the job's read count); duplicates, distinct counts and rows against the oracle"""
+    n = 120_000
+    w = workloads.make("config4", geo_total=n)
+    eng = _run(w, 0, n, chunk=50_000)
+    seq, qual = w.synth.generate_host(0, n)
+    o = workloads.oracle_for(w)
+    o.process_batch(seq, qual, w.read_len, w.read_len)
+    got = eng.counters()
+    for k, v in o.counters.items():
+        assert got[k] == v, (k, got, o.counters)
+    assert n // 4 < got["duplicates"] < 3 * n // 4  # mean 2 copies per molecule: about half of the passing reads
+    assert eng.result_rows() == o.rows()
+    eng.close()
+
+
 @pytest.mark.parametrize("variant", ["config3", "geometric", "zipf"])
 def test_synth_device_equals_host(variant):
     import torch

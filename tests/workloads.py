@@ -12,7 +12,7 @@ class Workload:
     pass
 
 
-def make(name, n_sets=None, lib=None, n_molecules=None, read_len=100, zipf=False, geo_total=0):
+def make(name, n_sets=None, lib=None, n_molecules=None, read_len=100, zipf=False, geo_total=0, synth_overrides=None):
     """name: config2 | config3 | config5.  n_sets = (samples, refs per counted barcode...) overrides the
     BASELINE sizes (tests use smaller sets so the CPU oracle stays fast)."""
     w = Workload()
@@ -71,6 +71,8 @@ def make(name, n_sets=None, lib=None, n_molecules=None, read_len=100, zipf=False
         w.min_quality = 0.0
     else:
         raise KeyError(name)
+    if synth_overrides:  # e.g. heavier error rates than the BASELINE model (parity tests of the deep search tiers)
+        w.synth_args.update(synth_overrides)
     w.plan = plan
     w.synth = pkg.Synth(plan, read_len=w.read_len, **w.synth_args)
     return w
