@@ -31,6 +31,7 @@ extern "C" {
 #define BC_ERR_HIP (-3)         /* HIP runtime failure */
 #define BC_ERR_NOMEM (-4)
 #define BC_ERR_STATE (-5)       /* call order violated */
+#define BC_ERR_COMM (-6)        /* the exchange between the ranks of a multi-GPU job failed (a peer is gone, I/O) */
 
 /* outcome counters: SequenceErrors (info.rs:16-23) in Display order (info.rs:141-172),
  * then two engine-side extras */
@@ -209,6 +210,40 @@ int bc_table_pack_u8(const void *d_table_u32, uint64_t n, void *d_out_u8, void *
  * (n a multiple of 4). */
 int bc_table_sum_u8(const void *d_rows_u8, uint32_t n_rows, uint64_t n, void *d_out_u32, int device_id, void *hip_stream);
 
+/* ---- several GPUs: one process (or thread) per GPU, one exchange at the end of the job ----------
+ * The reference is one process whose workers share one Results map (main.rs:93-120).  Across GPUs every rank counts
+ * its own shard of the reads into its own engine -- no communication on the data path -- and the job ends with ONE
+ * collective call on every rank, after which the root's engine holds the job's result:
+ *   - dense table, no random barcode: the u32 tables are summed onto the root (all-to-all of byte-packed slices, local
+ *     sums, slices to the root: one xGMI link per peer, never a ring);
+ *   - random barcode: the (tuple, random) keys first go to one owner rank each, where duplicates across ranks collapse
+ *     (a sum of set sizes would be wrong, output.rs:265-270); the owners' per-tuple distinct counts then add up;
+ *   - captures kept raw: every rank's (key, count) pairs / keys go to the root's map.
+ * A communicator is either RCCL over xGMI (bc_comm_create: ncclSend / ncclRecv on the engine's stream; rank 0 makes the
+ * id with bc_comm_unique_id and hands its BC_COMM_ID_BYTES bytes to the other ranks by whatever means the caller has --
+ * a file, a pipe, MPI) or message files in a directory all ranks can write to (bc_comm_create_host: works between any
+ * processes of one machine, several ranks on ONE GPU included; device buffers are staged through host memory).
+ * counters (may be NULL): the job's outcome counters on the root, zeros elsewhere.  The tables of the other ranks are
+ * left in an unspecified state.  Tables must be 16-byte aligned (engine-owned ones are). */
+typedef struct bc_comm bc_comm;
+#define BC_COMM_ID_BYTES 128
+int bc_comm_unique_id(void *id_out);
+bc_comm *bc_comm_create(const void *id, int rank, int world, int device_id);
+bc_comm *bc_comm_create_host(const char *dir, int rank, int world);
+void bc_comm_destroy(bc_comm *c);
+int bc_comm_rank(const bc_comm *c);
+int bc_comm_world(const bc_comm *c);
+int bc_comm_barrier(bc_comm *c);
+/* element-wise sum of n u64 onto the root (e.g. the shards' "Total sequences"); the other ranks' values stay */
+int bc_comm_sum_u64(bc_comm *c, uint64_t *vals, int n, int root);
+/* the exchange alone: afterwards the root's table / key set / key map is the job's */
+int bc_engine_reduce_all(bc_engine *e, bc_comm *c, int root, uint64_t counters[BC_NCOUNTERS]);
+/* ... followed by bc_engine_finish on the root (rows readable there; *n_rows = 0 on the other ranks).  c = NULL or a
+ * communicator of one rank: the same as bc_engine_counters + bc_engine_finish. */
+int bc_engine_finish_all(bc_engine *e, bc_comm *c, int root, uint64_t counters[BC_NCOUNTERS], uint64_t *n_rows);
+/* the plan an engine was created from */
+const bc_plan *bc_engine_plan(const bc_engine *e);
+
 /* Debug / parity-test hook: the next submits also write, for read i of the submit, its outcome
  * (BC_* counter index; BC_MATCHED = passed every test) to d_outcome_u8[i] and its dense table index
  * to d_index_u64[i].  Both device pointers; NULL switches tracing off. */
@@ -270,6 +305,14 @@ int64_t bc_fix_error(const char *mismatch_seq, const char *const *possible_seqs,
  * wrong extension (input.rs:36-39), unreadable file, first record not FASTQ (parse.rs:377-394). */
 typedef void (*bc_progress_fn)(uint64_t total_reads, void *user);
 int bc_fastq_count(bc_engine *e, const char *fastq_path, uint64_t *total_reads, bc_progress_fn progress, void *user);
+/* One shard of n_shards (one per GPU of a job): the records that start inside this shard's share of the file's bytes.
+ * Shard boundaries are moved to the next record start ('@' line whose second-next line begins with '+'), so the shards
+ * tile the file's records exactly and their totals add up to bc_fastq_count's -- for a file whose lines come in fours;
+ * one that does not is refused (BC_ERR_INVALID: the reference frames from the file's first line, a shard cannot).  The
+ * first-record check is the first shard's, the trailing partial record the last shard's.  A .gz stream cannot be entered
+ * in the middle: shard 0 reads all of it, the others nothing. */
+int bc_fastq_count_shard(bc_engine *e, const char *fastq_path, uint32_t shard, uint32_t n_shards, uint64_t *total_reads,
+                         bc_progress_fn progress, void *user);
 
 /* ---- synthetic workloads (bench + full-size parity) -------------------------------------- */
 

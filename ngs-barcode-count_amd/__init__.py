@@ -18,7 +18,7 @@ import numpy as np
 from . import _lib
 from ._lib import COUNTER_NAMES, SynthParams
 
-__all__ = ["Plan", "Engine", "Synth", "SequenceFormat", "BarcodeConversions", "MaxSeqErrors", "SequenceErrors",
+__all__ = ["Plan", "Engine", "Comm", "Synth", "SequenceFormat", "BarcodeConversions", "MaxSeqErrors", "SequenceErrors",
            "Results", "SequenceParser", "fix_error", "BarcodeCountError", "COUNTER_NAMES"]
 
 
@@ -161,11 +161,14 @@ class Engine:
             lp = lens.ctypes.data
         _check(self._lib, self._lib.bc_engine_submit_host(self._e, seq.ctypes.data, qp, lp, stride, read_len, n))
 
-    def count_fastq(self, path):
+    def count_fastq(self, path, shard=0, n_shards=1):
         """input::read_fastq + the workers (input.rs:24-89, parse.rs:53-76): reads a .fastq / .fastq.gz
         file and counts it; returns the reference's "Total sequences" value"""
         n = C.c_uint64()
-        _check(self._lib, self._lib.bc_fastq_count(self._e, str(path).encode(), C.byref(n), None, None))
+        if n_shards == 1:
+            _check(self._lib, self._lib.bc_fastq_count(self._e, str(path).encode(), C.byref(n), None, None))
+        else:  # this GPU's share of the file's records (bc_fastq_count_shard)
+            _check(self._lib, self._lib.bc_fastq_count_shard(self._e, str(path).encode(), shard, n_shards, C.byref(n), None, None))
         return n.value
 
     def sync(self):
@@ -271,6 +274,20 @@ class Engine:
         _check(self._lib, rc)
         return n.value
 
+    def reduce_all(self, comm, root=0):
+        """bc_engine_reduce_all: the job's one exchange (collective over comm); -> the job's counters on the root,
+        zeros elsewhere.  Afterwards the root's engine holds the job's table / key set / key map."""
+        out = (C.c_uint64 * 8)()
+        _check(self._lib, self._lib.bc_engine_reduce_all(self._e, comm._c if comm is not None else None, root, out))
+        return dict(zip(COUNTER_NAMES, [int(x) for x in out]))
+
+    def finish_all(self, comm, root=0):
+        """bc_engine_finish_all = reduce_all + finish on the root; -> (counters, number of rows)"""
+        out = (C.c_uint64 * 8)()
+        n = C.c_uint64()
+        _check(self._lib, self._lib.bc_engine_finish_all(self._e, comm._c if comm is not None else None, root, out, C.byref(n)))
+        return dict(zip(COUNTER_NAMES, [int(x) for x in out])), n.value
+
     def finish(self):
         """bc_engine_finish: compacts the results into sparse rows; returns their number"""
         n = C.c_uint64()
@@ -308,6 +325,59 @@ class Engine:
         for i in range(len(c)):
             out.append((samples[s[i]], ",".join(sets[j][b[i, j]] for j in range(len(sets))), int(c[i])))
         return sorted(out)
+
+
+class Comm:
+    """The communicator of a multi-GPU job (bc_comm): one rank per GPU, ONE exchange at the job's end.
+    Comm.rccl(id, rank, world, device): RCCL over xGMI -- rank 0 makes `id` with Comm.unique_id() and hands the bytes to
+    the others (a file, a pipe, torch.distributed ...).  Comm.host(dir, rank, world): message files in a directory every
+    rank can write to (any processes of one machine, several ranks on one GPU included)."""
+
+    def __init__(self, handle, lib):
+        self._c, self._lib = handle, lib
+
+    @staticmethod
+    def unique_id(lib=None):
+        lib = lib or _lib.load()
+        buf = C.create_string_buffer(_lib.BC_COMM_ID_BYTES)
+        _check(lib, lib.bc_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def rccl(cls, unique_id, rank, world, device, lib=None):
+        lib = lib or _lib.load()
+        assert len(unique_id) == _lib.BC_COMM_ID_BYTES
+        h = lib.bc_comm_create(C.create_string_buffer(bytes(unique_id), _lib.BC_COMM_ID_BYTES), rank, world, int(device))
+        if not h:
+            raise BarcodeCountError(_lib.BC_ERR_COMM, _lib.last_error(lib))
+        return cls(h, lib)
+
+    @classmethod
+    def host(cls, directory, rank, world, lib=None):
+        lib = lib or _lib.load()
+        h = lib.bc_comm_create_host(str(directory).encode(), rank, world)
+        if not h:
+            raise BarcodeCountError(_lib.BC_ERR_COMM, _lib.last_error(lib))
+        return cls(h, lib)
+
+    rank = property(lambda s: s._lib.bc_comm_rank(s._c))
+    world = property(lambda s: s._lib.bc_comm_world(s._c))
+
+    def barrier(self):
+        _check(self._lib, self._lib.bc_comm_barrier(self._c))
+
+    def sum_u64(self, values, root=0):
+        """element-wise sum of a list of ints onto the root (the other ranks get their own values back)"""
+        arr = (C.c_uint64 * len(values))(*values)
+        _check(self._lib, self._lib.bc_comm_sum_u64(self._c, arr, len(values), root))
+        return [int(x) for x in arr]
+
+    def close(self):
+        if getattr(self, "_c", None):
+            self._lib.bc_comm_destroy(self._c)
+            self._c = None
+
+    __del__ = close
 
 
 class Synth:

@@ -7,7 +7,8 @@ CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libbarcode_count_hip.so")
 
 BC_OK = 0
-BC_ERR_INVALID, BC_ERR_UNSUPPORTED, BC_ERR_HIP, BC_ERR_NOMEM, BC_ERR_STATE = -1, -2, -3, -4, -5
+BC_ERR_INVALID, BC_ERR_UNSUPPORTED, BC_ERR_HIP, BC_ERR_NOMEM, BC_ERR_STATE, BC_ERR_COMM = -1, -2, -3, -4, -5, -6
+BC_COMM_ID_BYTES = 128
 COUNTER_NAMES = ["matched", "constant_region", "sample_barcode", "barcode", "duplicates", "low_quality",
                  "total_reads", "unsupported_reads"]
 
@@ -97,8 +98,20 @@ ENGINE_API = {
     "bc_engine_materialize_table": (_int, [_vp]),
     "bc_engine_export_counts": (_int, [_vp, _vp, _vp, _u64, C.POINTER(_u64)]),
     "bc_engine_import_counts": (_int, [_vp, _vp, _vp, _u64]),
+    "bc_comm_unique_id": (_int, [_vp]),
+    "bc_comm_create": (_vp, [_vp, _int, _int, _int]),
+    "bc_comm_create_host": (_vp, [_cp, _int, _int]),
+    "bc_comm_destroy": (None, [_vp]),
+    "bc_comm_rank": (_int, [_vp]),
+    "bc_comm_world": (_int, [_vp]),
+    "bc_comm_barrier": (_int, [_vp]),
+    "bc_engine_reduce_all": (_int, [_vp, _vp, _int, C.POINTER(C.c_uint64)]),
+    "bc_engine_finish_all": (_int, [_vp, _vp, _int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "bc_engine_plan": (_vp, [_vp]),
     "bc_fix_error": (C.c_int64, [_cp, C.POINTER(_cp), _u64, C.c_uint16, _int]),
     "bc_fastq_count": (_int, [_vp, _cp, C.POINTER(C.c_uint64), _vp, _vp]),
+    "bc_fastq_count_shard": (_int, [_vp, _cp, _u32, _u32, C.POINTER(C.c_uint64), _vp, _vp]),
+    "bc_comm_sum_u64": (_int, [_vp, C.POINTER(C.c_uint64), _int, _int]),
     "bc_synth_create": (_vp, [_vp, C.POINTER(SynthParams)]),
     "bc_synth_destroy": (None, [_vp]),
     "bc_synth_generate_host": (_int, [_vp, _u64, _u64, _vp, _vp, _u32]),

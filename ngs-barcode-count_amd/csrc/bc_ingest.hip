@@ -469,6 +469,9 @@ struct Source {
       }
       return (long)got;
     }
+    // (size = where this reader's share of the file ends: the file's end, or the shard's)
+    if (pos >= size) return 0;
+    cap = (size_t)std::min<unsigned long long>(cap, size - pos);
     // page cache -> pinned memory, one slice per thread
     const size_t slice = ((cap / threads) + 4095) & ~(size_t)4095;
     std::vector<long> got(threads, 0);
@@ -501,10 +504,80 @@ struct Source {
   }
 };
 
+// First record of a plain FASTQ file that starts at or after byte `off`: the first line start p >= off whose line
+// begins with '@' while the line two further down begins with '+' (a quality line may begin with '@', but then the line
+// two further down is a sequence line, which never begins with '+').  `size` when there is none; -1 on a read error or
+// when no record boundary is found within 16 MiB (no FASTQ record is that long: the framing kernels allow 4 MiB).
+long long record_start_at_or_after(int fd, unsigned long long off, unsigned long long size) {
+  if (off == 0) return 0;
+  if (off >= size) return (long long)size;
+  const unsigned long long from = off - 1;  // (the byte before tells whether `off` itself starts a line)
+  std::vector<char> buf;
+  const size_t step = 1u << 20, limit = 16u << 20;
+  for (;;) {
+    const size_t have = buf.size();
+    if (from + have >= size || have >= limit) break;
+    const size_t want = (size_t)std::min<unsigned long long>(step, size - (from + have));
+    buf.resize(have + want);
+    size_t got = 0;
+    while (got < want) {
+      const ssize_t n = pread(fd, buf.data() + have + got, want - got, (off_t)(from + have + got));
+      if (n < 0) return -1;
+      if (n == 0) break;
+      got += (size_t)n;
+    }
+    buf.resize(have + got);
+    const bool at_end = from + buf.size() >= size;
+    // line starts inside the window (buffer offsets), from the first one at or after `off`
+    size_t p = 0;
+    if (buf[0] != '\n') {
+      const char* nl = (const char*)memchr(buf.data(), '\n', buf.size());
+      if (!nl) {
+        if (at_end) return (long long)size;
+        continue;  // one long line so far
+      }
+      p = (size_t)(nl - buf.data());
+    }
+    p += 1;  // first byte after a newline that sits at or after off - 1
+    bool need_more = false;
+    while (p < buf.size()) {
+      const char* e1 = (const char*)memchr(buf.data() + p, '\n', buf.size() - p);
+      const char* e2 = e1 ? (const char*)memchr(e1 + 1, '\n', buf.size() - (size_t)(e1 + 1 - buf.data())) : nullptr;
+      if (!e1 || !e2 || (size_t)(e2 + 1 - buf.data()) >= buf.size()) {
+        need_more = true;  // the line two further down is not in the window yet
+        break;
+      }
+      if (buf[p] == '@' && e2[1] == '+') return (long long)(from + p);
+      p = (size_t)(e1 + 1 - buf.data());
+    }
+    if (at_end) return (long long)size;  // fewer than three lines left: no whole record starts here
+    if (!need_more && p >= buf.size()) continue;
+    if (buf.size() >= limit) return -1;
+  }
+  return from + buf.size() >= size ? (long long)size : -1;
+}
+
 }  // namespace
+
+static int fastq_count_impl(bc_engine* e, const char* fastq_path, uint32_t shard, uint32_t n_shards, uint64_t* total_reads,
+                            bc_progress_fn progress, void* user);
 
 extern "C" int bc_fastq_count(bc_engine* e, const char* fastq_path, uint64_t* total_reads, bc_progress_fn progress,
                               void* user) {
+  return fastq_count_impl(e, fastq_path, 0, 1, total_reads, progress, user);
+}
+
+extern "C" int bc_fastq_count_shard(bc_engine* e, const char* fastq_path, uint32_t shard, uint32_t n_shards,
+                                    uint64_t* total_reads, bc_progress_fn progress, void* user) {
+  if (n_shards == 0 || shard >= n_shards) {
+    set_error("bc_fastq_count_shard: shard outside 0 .. n_shards-1");
+    return BC_ERR_INVALID;
+  }
+  return fastq_count_impl(e, fastq_path, shard, n_shards, total_reads, progress, user);
+}
+
+static int fastq_count_impl(bc_engine* e, const char* fastq_path, uint32_t shard, uint32_t n_shards, uint64_t* total_reads,
+                            bc_progress_fn progress, void* user) {
   if (total_reads) *total_reads = 0;
   const std::string path = fastq_path ? fastq_path : "";
   const bool gz = ends_with(path, "fastq.gz");
@@ -527,6 +600,28 @@ extern "C" int bc_fastq_count(bc_engine* e, const char* fastq_path, uint64_t* to
   if (!gz) {
     const off_t end = lseek(src.fd, 0, SEEK_END);
     src.size = end > 0 ? (unsigned long long)end : 0ull;
+  }
+  // One shard of several (one per GPU of a job): the records that START inside this shard's share of the bytes.  A gz
+  // stream cannot be entered in the middle: its first shard takes all of it, the others have nothing to read.
+  const bool last_shard = shard + 1 == n_shards;
+  if (n_shards > 1) {
+    if (gz) {
+      if (shard != 0) {
+        gzclose(src.zf);
+        return BC_OK;
+      }
+    } else {
+      const unsigned long long size = src.size;
+      const long long a = record_start_at_or_after(src.fd, size / n_shards * shard, size);
+      const long long b = last_shard ? (long long)size : record_start_at_or_after(src.fd, size / n_shards * (shard + 1), size);
+      if (a < 0 || b < 0) {
+        close(src.fd);
+        set_error("no FASTQ record boundary found near a shard boundary of " + path + " (read error, or not 4-line FASTQ)");
+        return BC_ERR_INVALID;
+      }
+      src.pos = (unsigned long long)a;
+      src.size = (unsigned long long)std::max(a, b);
+    }
   }
   src.threads = std::min(8u, std::max(1u, std::thread::hardware_concurrency() / 2));
   if (const char* ev = getenv("BC_INGEST_THREADS")) src.threads = (unsigned)std::min(64, std::max(1, atoi(ev)));
@@ -628,7 +723,7 @@ extern "C" int bc_fastq_count(bc_engine* e, const char* fastq_path, uint64_t* to
 
   uint64_t total = 0, lines_after_last_record = 0;
   bool last_byte_newline = true, any_bytes = false, appended_newline = false;
-  bool test = true;
+  bool test = shard == 0;  // (the file's first record is the first shard's)
   int pending = -1;  // chunk framed but not yet submitted
   for (int i = 0;; ++i) {
     {
@@ -728,6 +823,13 @@ extern "C" int bc_fastq_count(bc_engine* e, const char* fastq_path, uint64_t* to
       return finish(BC_ERR_UNSUPPORTED);
     }
     (void)appended_newline;
+    if (!last_shard && !(gz && shard == 0) && seen != 0) {
+      // a shard that does not end the file ends on a record boundary; lines left over mean the file's lines do not
+      // come in fours from where this shard started -- the reference, framing from the file's first line, would read
+      // it differently from here on
+      set_error("the lines of " + path + " do not come in records of four: run it on one GPU");
+      return finish(BC_ERR_INVALID);
+    }
     if (seen > 0 && seen < 4) total += 1;  // a trailing partial record is counted when its first line is seen (input.rs:128-130)
     if (gz) {
       // the gz loop calls read("") once more at EOF (input.rs:69-73): when that lands on "line 1" the total grows

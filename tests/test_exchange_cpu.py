@@ -1,0 +1,112 @@
+"""The multi-GPU job's end-of-run exchange (csrc/bc_exchange.hpp) on CPU ranks: the SAME slicing / byte-packing /
+overflow / owner-partition / gather logic the engine runs on device buffers (csrc/bc_comm.hip), instantiated here over
+host buffers (tests/emu/exchange_host.cpp) and run by 2, 3 and 5 processes over the message-file transport of
+csrc/bc_comm.hpp.  Expected results are recomputed independently in numpy."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "ngs-barcode-count_amd", "csrc")
+EXE = os.path.join(ROOT, "tests", "emu", "exchange_host")
+SRC = os.path.join(ROOT, "tests", "emu", "exchange_host.cpp")
+DEPS = [SRC, os.path.join(CSRC, "bc_exchange.hpp"), os.path.join(CSRC, "bc_comm.hpp")]
+
+M64 = (1 << 64) - 1
+
+
+def _build():
+    if not os.path.exists(EXE) or any(os.path.getmtime(d) > os.path.getmtime(EXE) for d in DEPS):
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-o", EXE, SRC])
+    return EXE
+
+
+def _mix(x):
+    x = np.asarray(x, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = x ^ (x >> np.uint64(30))
+        x = x * np.uint64(0xBF58476D1CE4E5B9)
+        x = x ^ (x >> np.uint64(27))
+        x = x * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+    return x
+
+
+def _table(seed, r, n):
+    with np.errstate(over="ignore"):
+        h = _mix(np.uint64(seed) * np.uint64(1000003) + np.uint64(r) * np.uint64(7919) + np.arange(n, dtype=np.uint64))
+    kind = (h & np.uint64(1023)).astype(np.int64)
+    hi = (h >> np.uint64(10))
+    out = np.zeros(n, dtype=np.uint64)
+    small = (kind >= 700) & (kind < 1000)
+    out[small] = (hi[small] & np.uint64(7)) + np.uint64(1)
+    mid = (kind >= 1000) & (kind < 1020)
+    out[mid] = np.uint64(200) + (hi[mid] & np.uint64(127))
+    big = kind >= 1020
+    out[big] = np.uint64(0xFFFFFF00) + (hi[big] & np.uint64(255))
+    return out.astype(np.uint32)
+
+
+def _run_ranks(tmp_path, world, args_of):
+    exe = _build()
+    d = tmp_path / "msgs"
+    d.mkdir()
+    procs = [subprocess.Popen([exe, str(d), str(r), str(world)] + args_of(r), stderr=subprocess.PIPE) for r in range(world)]
+    for r, p in enumerate(procs):
+        _, err = p.communicate(timeout=120)
+        assert p.returncode == 0, (r, err.decode()[-500:])
+    assert os.listdir(d) == []  # every message was consumed
+
+
+@pytest.mark.parametrize("world,n,root", [(2, 4096, 0), (3, 10_001, 2), (5, 777, 1), (2, 3, 1), (4, 2, 0)])
+def test_tables_are_summed_onto_the_root(tmp_path, world, n, root):
+    """table lengths that do and do not divide by 4 x world, slices that come out empty, counts on both sides of the
+    byte limit, u32 sums that wrap"""
+    out = tmp_path / "sum.bin"
+    _run_ranks(tmp_path, world, lambda r: ["tables", str(n), "42", str(root), str(out)])
+    raw = np.fromfile(out, dtype=np.uint8)
+    got = raw[: 4 * n].view(np.uint32)
+    counters = raw[4 * n:].view(np.uint64)
+    exp = np.zeros(n, dtype=np.uint32)
+    with np.errstate(over="ignore"):
+        for r in range(world):
+            exp = exp + _table(42, r, n)  # u32 arithmetic: wraps like the engine's atomics
+    assert np.array_equal(got, exp)
+    assert counters.tolist() == [world * (world + 1) // 2, 10 * world, n * world]
+
+
+def _key_owner(keys, world):
+    with np.errstate(over="ignore"):
+        x = keys * np.uint64(0x9E3779B97F4A7C15)
+    x = x ^ (x >> np.uint64(32))
+    return ((x >> np.uint64(7)) % np.uint64(world)).astype(np.int64)
+
+
+@pytest.mark.parametrize("world,n,root", [(2, 5000, -1), (3, 4001, -1), (3, 1000, 1), (4, 0, -1)])
+def test_keys_reach_their_owner(tmp_path, world, n, root):
+    """hashed ownership (random-barcode plans: duplicates across ranks meet on one rank) and everything-to-the-root
+    (raw-key plans); the u32 travelling with each key stays with it"""
+    out = tmp_path / "keys"
+    _run_ranks(tmp_path, world, lambda r: ["keys", str(n), "7", str(root), str(out)])
+    sent = []
+    for r in range(world):
+        i = np.arange(n, dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            keys = _mix(np.uint64(7) + (i * np.uint64(3) + np.uint64(r)) % np.uint64(2 * n + 1))
+        vals = (r * 1000 + (np.arange(n) % 7)).astype(np.uint32)
+        sent.append((keys, vals))
+    rec = np.dtype([("k", "<u8"), ("v", "<u4")])
+    for r in range(world):
+        got = np.fromfile(str(out) + ".%d" % r, dtype=rec)
+        exp = []
+        for keys, vals in sent:
+            own = _key_owner(keys, world) if root < 0 else np.full(n, root)
+            exp += list(zip(keys[own == r].tolist(), vals[own == r].tolist()))
+        assert sorted(zip(got["k"].tolist(), got["v"].tolist())) == sorted(exp)
+    if root < 0 and n:
+        # the point of ownership: equal keys from different ranks ended up on the same rank
+        allk = np.concatenate([k for k, _ in sent])
+        assert len(np.unique(allk)) < len(allk)

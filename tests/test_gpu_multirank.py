@@ -1,0 +1,73 @@
+"""The multi-GPU job end to end THROUGH THE C ABI on the one GPU this box has: several processes, each with its own
+engine on device 0 and its own shard of the reads, joined by bc_comm_create_host + bc_engine_finish_all (the
+message-file transport; on a multi-GPU node the same exchange runs over RCCL).  The root's counters and rows must equal
+the oracle's over ALL reads -- dense tables (incl. counts above the byte-packing limit), the random-barcode key
+exchange, and both raw-key forms."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(case, n):
+    import oracle_lib
+    import workloads
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import mp_rank
+    w = mp_rank.make_case(case)
+    seq, qual = w.synth.generate_host(0, n)
+    if case.startswith("sparse"):
+        o = oracle_lib.Oracle(w.scheme)
+    else:
+        o = workloads.oracle_for(w)
+    o.process_batch(seq, qual if w.min_quality > 0 else None, w.read_len, w.read_len)
+    return o.counters, o.rows()
+
+
+@pytest.mark.parametrize("case,world,n,root", [("dense", 2, 60_001, 0), ("dense", 3, 40_000, 2), ("dense_hot", 2, 50_000, 1),
+                                               ("random", 2, 60_000, 0), ("random", 3, 45_000, 1),
+                                               ("sparse", 2, 30_000, 0), ("sparse_random", 3, 30_000, 2)])
+def test_ranks_on_one_gpu_equal_the_oracle(tmp_path, case, world, n, root):
+    cdir = tmp_path / "comm"
+    cdir.mkdir()
+    out = tmp_path / "job.json"
+    env = dict(os.environ, BC_COMM_TIMEOUT_S="120")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_rank.py"), case, str(r), str(world), str(cdir),
+                               str(n), str(root), str(out)], env=env, stderr=subprocess.PIPE) for r in range(world)]
+    for r, p in enumerate(procs):
+        _, err = p.communicate(timeout=300)
+        assert p.returncode == 0, (r, err.decode()[-1500:])
+    job = json.load(open(out))
+    exp_counters, exp_rows = _oracle(case, n)
+    assert {k: job["counters"][k] for k in exp_counters} == exp_counters
+    assert job["counters"]["total_reads"] == n
+    assert [tuple(r) for r in job["rows"]] == exp_rows
+    if case == "dense_hot":
+        assert max(r[2] for r in job["rows"]) > 255 * world  # the side list really was needed
+    if case.startswith("random") or case == "sparse_random":
+        assert job["counters"]["duplicates"] > n // 10
+
+
+def test_one_rank_communicator_is_a_plain_finish(tmp_path):
+    import torch
+    import ngs_barcode_count_amd as pkg
+    import workloads
+    w = workloads.make("config3", n_sets=(4, 30, 30, 30))
+    n, R = 20_000, w.read_len
+    seq, qual = w.synth.generate_host(0, n)
+    eng = pkg.Engine(w.plan, device=0)
+    eng.submit_host(seq, qual, R, R)
+    comm = pkg.Comm.host(str(tmp_path), 0, 1)
+    counters, rows = eng.finish_all(comm, 0)
+    o = workloads.oracle_for(w)
+    o.process_batch(seq, qual, R, R)
+    assert {k: counters[k] for k in o.counters} == o.counters and rows == len(o.rows())
+    assert eng.result_rows() == o.rows()
+    c2, r2 = eng.finish_all(None, 0)  # no communicator at all
+    assert c2 == counters and r2 == rows
+    eng.close()
