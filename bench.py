@@ -204,7 +204,7 @@ class Run:
     contract's numbers (rank 0: complete); the legs that are NOT part of the headline (finish, box ceilings, host
     submit, ingest) are separate methods that main() calls only after the contract line is out."""
 
-    def __init__(self, name, n, steps, warmup, world, rank, local, dev):
+    def __init__(self, name, n, steps, warmup, world, rank, local, dev, comm=None):
         import torch
         import ngs_barcode_count_amd as pkg
         from ngs_barcode_count_amd import distributed as bcdist
@@ -225,11 +225,10 @@ class Run:
         self.with_qual = w.min_quality > 0
         self.random_mode = w.plan.random_barcode
         # The counters come first: the table is the randomly accessed allocation and gets the device memory of a fresh
-        # process; the resident batches then take what is left.  N > 1: the table is this process's own tensor, so that
-        # the job's end-of-run exchange can read it; N = 1: the engine owns it, as in the command-line program.
-        self.table = torch.zeros(w.plan.table_entries, dtype=torch.int32, device=dev) if world > 1 else None
-        torch.cuda.synchronize()
-        self.eng = pkg.Engine(w.plan, device=local, table_ptr=self.table.data_ptr() if self.table is not None else None)
+        # process; the resident batches then take what is left.  The engine owns its table at every N, as in the
+        # command-line program: the end-of-run exchange goes through the C ABI (bc_engine_reduce_all).
+        self.eng = pkg.Engine(w.plan, device=local)
+        self.comm = comm  # N > 1: the job's communicator (bc_comm: RCCL over xGMI), made once per process in main()
         # --- resident inputs: this rank's contiguous shard of the seeded read stream, one batch per step ------------
         # Every step counts reads it has not seen before (a job never counts the same batch twice), as many distinct
         # batches as the HBM holds next to the counters and the working memory of everything this process does later
@@ -251,7 +250,6 @@ class Run:
     def close(self):
         self.eng.close()
         self.batches = []
-        self.table = None
         self.torch.cuda.empty_cache()
 
     def _barrier(self):
@@ -261,7 +259,7 @@ class Run:
             self.torch.distributed.barrier()
 
     def measure(self):
-        torch, pkg, bcdist, eng, w = self.torch, self.pkg, self.bcdist, self.eng, self.w
+        torch, pkg, eng, w = self.torch, self.pkg, self.eng, self.w
         dist = torch.distributed
         n, R, steps, world, rank, dev = self.n, self.R, self.steps, self.world, self.rank, self.dev
         step_no = [0]
@@ -288,9 +286,7 @@ class Run:
             step()
         if world > 1:
             # warm-up of the end-of-job exchange too: RCCL sets up its peer-to-peer connections on first use
-            if self.random_mode:
-                bcdist.exchange_keys(torch.arange(world * 64, dtype=torch.int64, device=dev))
-            bcdist.reduce_table(torch.ones(world * 4096, dtype=torch.int32, device=dev), dst=0)
+            eng.reduce_all(self.comm, 0)
         self._barrier()
         t_r = time.perf_counter()
         eng.reset()
@@ -308,15 +304,13 @@ class Run:
         eng.sync()  # (a caller-owned table: folds the first-occurrence bits into it -- part of the job, inside the region)
         t_steps = time.perf_counter() - t0
         reduce_ms = 0.0
-        fixed_counters = None
+        job_counters = None
         if world > 1:
+            # the job's one exchange, through the C ABI: dense tables summed onto the root (all-to-all of byte-packed
+            # slices over xGMI); random-barcode mode: keys to their owner ranks first, then the owners' per-tuple
+            # distinct counts are summed
             tr = time.perf_counter()
-            if self.random_mode:
-                # set sizes do not add: exchange the keys so that each has one owner; every rank then
-                # turns its keys into per-tuple distinct counts and those tables are summed onto the root
-                fixed_counters = bcdist.finish_random(eng, dev, dst=0, table=self.table)
-            else:
-                bcdist.reduce_table(self.table, dst=0)  # the job's one exchange: all-to-all sum of the counter tables
+            job_counters = eng.reduce_all(self.comm, 0)
             torch.cuda.synchronize()
             reduce_ms = (time.perf_counter() - tr) * 1e3
         self._barrier()
@@ -330,13 +324,14 @@ class Run:
         each = eng.kernel_ms_each()
         kernel_ms, launches = eng.kernel_ms()
         eng.timing(False)
-        if fixed_counters is not None:
-            counters = fixed_counters
+        if job_counters is not None:
+            # (the counters of the passes before a reset never went through the exchange: add them up separately)
+            extra = self.comm.sum_u64([carried[k] for k in pkg.COUNTER_NAMES], 0)
+            counters = {k: job_counters[k] + extra[i] for i, k in enumerate(pkg.COUNTER_NAMES)}
         else:
-            local_counters = eng.counters()
+            counters = eng.counters()
             for key in carried:
-                local_counters[key] += carried[key]
-            counters = bcdist.reduce_counters(local_counters, dev, dst=0)
+                counters[key] += carried[key]
         if rank != 0:
             return None
         total_reads = n * steps * world
@@ -531,8 +526,18 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    comm = None
+    if world > 1:
+        # the engine library's own communicator (bc_comm over RCCL): rank 0 makes the id, torch.distributed -- which the
+        # timing contract needs anyway for its barrier and its max over ranks -- carries it to the others
+        import ngs_barcode_count_amd as pkg
+        ident = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            ident.copy_(torch.frombuffer(bytearray(pkg.Comm.unique_id()), dtype=torch.uint8))
+        dist.broadcast(ident, src=0)
+        comm = pkg.Comm.rccl(bytes(ident.cpu().numpy().tobytes()), rank, world, local)
     n = args.reads or DEFAULT_READS[args.config]
-    run = Run(args.config, n, args.steps, args.warmup, world, rank, local, dev)
+    run = Run(args.config, n, args.steps, args.warmup, world, rank, local, dev, comm)
     res = run.measure()
     if rank != 0:
         run.close()
@@ -556,7 +561,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": res["workload"], "config": args.config, "reads_per_step_per_gpu": n, "read_len": res["read_len"],
                    "distinct_batches": res["distinct_batches"], "resets_in_region": res["resets_in_region"],
-                   "parallelism": "reads sharded over %d GPU(s); one all-to-all sum of the counter tables over xGMI at the end" % world},
+                   "parallelism": "reads sharded over %d GPU(s), one process each; one exchange at the end through the C ABI "
+                                  "(bc_engine_reduce_all: all-to-all sum of the counter tables, RCCL over xGMI)" % world},
         "roofline": res["roofline"],
         "outcomes": res["outcomes"],
         "reduce_ms": res["reduce_ms"],

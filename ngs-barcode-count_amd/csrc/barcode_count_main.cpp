@@ -6,12 +6,27 @@
 // reader thread and the worker pool of main.rs:69-121 are replaced by bc_fastq_count + the gfx950
 // engine.  Row order inside the CSVs is unspecified in the reference (HashMap iteration); here rows
 // come out in the engine's index order.  `--threads` is accepted and ignored (no CPU workers exist).
+//
+// `--gpus N` (no counterpart in the reference, which is one process): the process started by the user never touches
+// a GPU; it starts N rank processes of this same program, one per GPU, and passes rank 0's output through.  Every
+// rank counts its share of the FASTQ file's records (bc_fastq_count_shard) and the job ends with the one exchange of
+// bc_engine_finish_all -- RCCL over xGMI between the GPUs (rank 0's unique id travels through a file in a private
+// temporary directory), or, with `--comm host`, message files in that directory (several ranks on one GPU).
+#include <errno.h>
+#include <fcntl.h>
+#include <spawn.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <sys/time.h>
+#include <sys/wait.h>
 #include <time.h>
+#include <unistd.h>
+
+#include <dirent.h>
+#include <signal.h>
 
 #include <algorithm>
 #include <map>
@@ -22,6 +37,8 @@
 #include <vector>
 
 #include "../../include/barcode_count_hip.h"
+
+extern char** environ;
 
 namespace {
 
@@ -34,6 +51,12 @@ struct Args {  // arguments.rs:6-20
   int barcodes_errors = -1, sample_errors = -1, constant_errors = -1;
   float min_quality = 0.0f;
   int device = 0;
+  // several GPUs
+  int gpus = 1;
+  std::vector<int> devices;        // --devices a,b,..: the HIP device of each rank (default 0 .. gpus-1)
+  std::string comm = "rccl";       // --comm rccl | host
+  int rank = -1, world = 1;        // (set by the launcher for its rank processes)
+  std::string comm_dir;
 };
 
 [[noreturn]] void die(const char* fmt, ...) {
@@ -64,7 +87,10 @@ void usage() {
       "    -p, --prefix <prefix>                      File prefix name.  THe output will end with '_<sample_name>_counts.csv'\n"
       "    -s, --sample-barcodes <sample_file>        Sample barcodes file\n"
       "    -t, --threads <threads>                    Number of threads (ignored: the GPU engine has no CPU workers)\n"
-      "        --device <id>                          HIP device to run on [default: 0]\n");
+      "        --device <id>                          HIP device to run on [default: 0]\n"
+      "        --gpus <n>                             Run on n GPUs: one process per GPU, reads sharded, one exchange at the end [default: 1]\n"
+      "        --devices <a,b,..>                     The HIP device of each of the n ranks [default: 0,1,..]\n"
+      "        --comm <rccl|host>                     How the ranks exchange their results: RCCL over xGMI, or files in a temporary directory [default: rccl]\n");
 }
 
 int parse_u16(const char* what, const char* v) {
@@ -136,11 +162,33 @@ Args parse_args(int argc, char** argv) {
       if (s.empty() || *end != 0) die("Unable to convert min score to a float");
     } else if (k == "--device") {
       a.device = parse_u16("device", val().c_str());
+    } else if (k == "--gpus") {
+      a.gpus = parse_u16("gpus", val().c_str());
+      if (a.gpus < 1 || a.gpus > 64) die("--gpus must be between 1 and 64");
+    } else if (k == "--devices") {
+      const std::string list = val();
+      size_t at = 0;
+      while (at <= list.size()) {
+        const size_t c = list.find(',', at);
+        a.devices.push_back(parse_u16("device", list.substr(at, c == std::string::npos ? std::string::npos : c - at).c_str()));
+        if (c == std::string::npos) break;
+        at = c + 1;
+      }
+    } else if (k == "--comm") {
+      a.comm = val();
+      if (a.comm != "rccl" && a.comm != "host") die("--comm must be rccl or host");
+    } else if (k == "--bc-rank") {  // (the three below are how the launcher tells a rank process who it is)
+      a.rank = parse_u16("rank", val().c_str());
+    } else if (k == "--bc-world") {
+      a.world = parse_u16("world", val().c_str());
+    } else if (k == "--bc-comm-dir") {
+      a.comm_dir = val();
     } else {
       die("Found argument '%s' which wasn't expected, or isn't valid in this context", k.c_str());
     }
   }
   if (!have_fastq || !have_format) die("The following required arguments were not provided: --fastq <fastq> --sequence-format <format_file>");
+  if (!a.devices.empty() && (int)a.devices.size() != a.gpus) die("--devices names %zu devices for --gpus %d", a.devices.size(), a.gpus);
   return a;
 }
 
@@ -546,6 +594,98 @@ void progress(uint64_t total, void*) {  // input.rs:151-159 (printed every 10,00
   fflush(stdout);
 }
 
+// --gpus N: starts the N rank processes and waits for them.  Nothing here touches a GPU (no HIP call, and the engine
+// library is not even asked for a device), and nothing is exec'ed by a process that has: the ranks are fresh children.
+int launch_ranks(const Args& a, int argc, char** argv) {
+  const char* base = getenv("TMPDIR");
+  std::string dir = std::string(access("/dev/shm", W_OK) == 0 ? "/dev/shm" : (base && *base ? base : "/tmp")) + "/barcode-count-XXXXXX";
+  if (!mkdtemp(&dir[0])) die("cannot create a temporary directory for the ranks: %s", strerror(errno));
+  char self[4096];
+  const ssize_t sl = readlink("/proc/self/exe", self, sizeof self - 1);
+  if (sl <= 0) die("cannot find this program's own path");
+  self[sl] = 0;
+  std::vector<pid_t> pids;
+  for (int r = 0; r < a.gpus; ++r) {
+    std::vector<std::string> args(argv, argv + argc);
+    args[0] = self;
+    const int dev = a.devices.empty() ? r : a.devices[(size_t)r];
+    for (const char* extra : {"--bc-rank", "", "--bc-world", "", "--bc-comm-dir", "", "--device", ""}) args.push_back(extra);
+    args[args.size() - 7] = std::to_string(r);
+    args[args.size() - 5] = std::to_string(a.gpus);
+    args[args.size() - 3] = dir;
+    args[args.size() - 1] = std::to_string(dev);
+    std::vector<char*> av;
+    for (auto& s : args) av.push_back(&s[0]);
+    av.push_back(nullptr);
+    posix_spawn_file_actions_t fa;
+    posix_spawn_file_actions_init(&fa);
+    if (r != 0) posix_spawn_file_actions_addopen(&fa, 1, "/dev/null", O_WRONLY, 0);  // one voice on stdout: rank 0's
+    pid_t pid = 0;
+    const int rc = posix_spawn(&pid, self, &fa, nullptr, av.data(), environ);
+    posix_spawn_file_actions_destroy(&fa);
+    if (rc != 0) {
+      for (pid_t p : pids) kill(p, SIGTERM);
+      die("cannot start rank %d: %s", r, strerror(rc));
+    }
+    pids.push_back(pid);
+  }
+  int worst = 0;
+  for (size_t r = 0; r < pids.size(); ++r) {
+    int status = 0;
+    while (waitpid(pids[r], &status, 0) < 0 && errno == EINTR) {
+    }
+    const int code = WIFEXITED(status) ? WEXITSTATUS(status) : 128 + (WIFSIGNALED(status) ? WTERMSIG(status) : 0);
+    if (code != 0) {
+      fprintf(stderr, "Error: rank %zu ended with status %d\n", r, code);
+      if (worst == 0)  // its peers may be waiting for it in the exchange: do not leave them waiting
+        for (size_t q = r + 1; q < pids.size(); ++q) kill(pids[q], SIGTERM);
+    }
+    worst = std::max(worst, code);
+  }
+  // whatever is left of the ranks' messages, and the directory
+  const std::string cmd_dir = dir;
+  if (DIR* d = opendir(cmd_dir.c_str())) {
+    while (struct dirent* e = readdir(d))
+      if (e->d_name[0] != '.') unlink((cmd_dir + "/" + e->d_name).c_str());
+    closedir(d);
+  }
+  rmdir(cmd_dir.c_str());
+  return worst;
+}
+
+// a rank's communicator: RCCL (the unique id goes from rank 0 to the others through a file) or message files
+bc_comm* make_comm(const Args& a) {
+  if (a.comm == "host") {
+    bc_comm* c = bc_comm_create_host(a.comm_dir.c_str(), a.rank, a.world);
+    if (!c) die("%s", bc_last_error());
+    return c;
+  }
+  unsigned char id[BC_COMM_ID_BYTES];
+  const std::string path = a.comm_dir + "/rccl_id";
+  if (a.rank == 0) {
+    if (bc_comm_unique_id(id)) die("%s", bc_last_error());
+    const std::string tmp = path + ".part";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f || fwrite(id, 1, sizeof id, f) != sizeof id || fclose(f) != 0 || rename(tmp.c_str(), path.c_str()) != 0)
+      die("cannot write %s", path.c_str());
+  } else {
+    const double t0 = now_ms();
+    for (;;) {
+      FILE* f = fopen(path.c_str(), "rb");
+      if (f) {
+        const size_t n = fread(id, 1, sizeof id, f);
+        fclose(f);
+        if (n == sizeof id) break;
+      }
+      if (now_ms() - t0 > 300e3) die("rank 0 did not publish the communicator id");
+      usleep(2000);
+    }
+  }
+  bc_comm* c = bc_comm_create(id, a.rank, a.world, a.device);
+  if (!c) die("%s", bc_last_error());
+  return c;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -553,6 +693,9 @@ int main(int argc, char** argv) {
   const time_t start = time(nullptr);
   Run r;
   r.args = parse_args(argc, argv);
+  if (r.args.gpus > 1 && r.args.rank < 0) return launch_ranks(r.args, argc, argv);
+  const bool multi = r.args.rank >= 0 && r.args.world > 1;
+  const bool root = !multi || r.args.rank == 0;
 
   const std::string scheme = read_file(r.args.format, "Failed to open");
   r.plan = bc_plan_create(scheme.data(), scheme.size());
@@ -584,9 +727,27 @@ int main(int argc, char** argv) {
     printf("If this program stops reading before the expected number of sequencing reads, unzip the gzipped fastq and rerun.\n\n");
   }
   uint64_t total_reads = 0;
-  if (bc_fastq_count(r.engine, r.args.fastq.c_str(), &total_reads, progress, nullptr)) die("Read Fastq error: %s", bc_last_error());
   uint64_t counters[BC_NCOUNTERS];
-  if (bc_engine_counters(r.engine, counters)) die("%s", bc_last_error());
+  uint64_t n_rows = 0;
+  if (!multi) {
+    if (bc_fastq_count(r.engine, r.args.fastq.c_str(), &total_reads, progress, nullptr)) die("Read Fastq error: %s", bc_last_error());
+    if (bc_engine_counters(r.engine, counters)) die("%s", bc_last_error());
+  } else {
+    // this rank's share of the records, then the job's one exchange; the root goes on to write the job's files
+    bc_comm* comm = make_comm(r.args);
+    if (bc_fastq_count_shard(r.engine, r.args.fastq.c_str(), (uint32_t)r.args.rank, (uint32_t)r.args.world, &total_reads,
+                             root ? progress : nullptr, nullptr))
+      die("Read Fastq error: %s", bc_last_error());
+    if (bc_comm_sum_u64(comm, &total_reads, 1, 0)) die("%s", bc_last_error());
+    if (bc_engine_finish_all(r.engine, comm, 0, counters, &n_rows)) die("%s", bc_last_error());
+    if (bc_comm_barrier(comm)) die("%s", bc_last_error());  // nobody leaves while a peer still reads its messages
+    bc_comm_destroy(comm);
+    if (!root) {
+      bc_engine_destroy(r.engine);
+      bc_plan_destroy(r.plan);
+      return 0;
+    }
+  }
   printf("Total sequences:             %s\r\n", commas((uint32_t)total_reads).c_str());  // input.rs:85-87
   printf("%s\n\n", errors_display(counters).c_str());                                      // main.rs:124
   printf("Compute time: %s\n\n", elapsed_text(now_ms() - start_ms).c_str());              // main.rs:127-135
@@ -601,8 +762,7 @@ int main(int argc, char** argv) {
   const bool sample_group = bc_plan_has_sample(r.plan) != 0;
   for (const auto& s : r.samples) r.sample_keys.push_back(s.first);
   if (r.samples.empty() && !sample_group) r.sample_keys.push_back("barcode");
-  uint64_t n_rows = 0;
-  if (bc_engine_finish(r.engine, &n_rows)) die("%s", bc_last_error());
+  if (!multi && bc_engine_finish(r.engine, &n_rows)) die("%s", bc_last_error());
   r.counted_map.resize(r.counted.size());
   for (size_t b = 0; b < r.counted.size(); ++b)
     for (const auto& kv : r.counted[b]) r.counted_map[b][kv.first] = kv.second;

@@ -250,3 +250,82 @@ def test_quality_line_of_another_length_than_the_sequence_line(tmp_path):
     assert total == len(reads)
     assert {k: got[k] for k in o.counters} == o.counters and rows == o.rows()
     assert o.counters["low_quality"] > 0 and o.counters["matched"] > 0
+
+
+@pytest.mark.parametrize("name,gpus,gz,qual_at", [("del_mismatch_quality", 2, False, True), ("del_random", 3, False, False),
+                                                  ("raw_counted", 2, False, False), ("crispr", 3, False, True),
+                                                  ("del_mismatch_quality", 2, True, False)])
+def test_cli_on_several_ranks_writes_what_one_rank_writes(tmp_path, name, gpus, gz, qual_at):
+    """`barcode-count --gpus N`: a launcher that never touches the GPU, N rank processes (here all on device 0, joined by
+    the message-file transport: the box has one GPU), every rank its share of the file's records, one exchange at the end
+    (bc_fastq_count_shard + bc_engine_finish_all).  Same files, rows, counters and totals as the oracle -- with quality
+    lines that begin with '@' where a shard boundary could mistake them for a header, and for a .gz input (which only the
+    first rank can read)"""
+    c = cases.build_case(name, seed=41, n=3001)
+    if qual_at:  # quality lines starting with '@' (Phred 31): legal, and the classic trap of FASTQ splitting
+        c["reads"] = [(s, ("@" + q[1:]) if q and i % 3 == 0 else q) for i, (s, q) in enumerate(c["reads"])]
+    tmp = str(tmp_path)
+    args = write_inputs(tmp, c, gz=gz)
+    out = os.path.join(tmp, "out")
+    os.makedirs(out)
+    cmd = [CLI] + args + ["-o", out, "-p", "multi", "-m", "--gpus", str(gpus), "--devices", ",".join(["0"] * gpus), "--comm", "host"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, BC_INGEST_CHUNK="65536"))
+    assert res.returncode == 0, res.stderr + res.stdout
+    o, w = expected(c, "multi", True, False)
+    produced = sorted(f for f in os.listdir(out) if f.endswith(".csv"))
+    assert produced == sorted(w.files), (produced, sorted(w.files))
+    for fn, (header, rows) in w.files.items():
+        h, r = read_csv(os.path.join(out, fn))
+        if ".all." in fn:
+            assert canonical(h, r, o.barcode_num) == canonical(header, rows, o.barcode_num), fn
+        else:
+            assert (h, r) == (header, rows), fn
+    total = len(c["reads"]) + (1 if gz else 0)
+    assert ("Total sequences:             {:,}".format(total)) in res.stdout
+    for label, key in (("Correctly matched sequences: ", "matched"), ("Constant region mismatches:  ", "constant_region"),
+                       ("Sample barcode mismatches:   ", "sample_barcode"), ("Counted barcode mismatches:  ", "barcode"),
+                       ("Duplicates:                  ", "duplicates"), ("Low quality barcodes:        ", "low_quality")):
+        assert label + "{:,}".format(o.counters[key]) in res.stdout, label
+    assert res.stdout.count("-FORMAT-") == 1  # one voice: rank 0's
+
+
+def test_fastq_shards_tile_the_file(tmp_path, monkeypatch):
+    """bc_fastq_count_shard: for 1..7 shards the shards' totals and counters add up to the whole file's, whatever the
+    shard boundaries fall on (mid-header, mid-quality line, on a quality line that begins with '@'); a file whose lines
+    do not come in fours is refused by the shard that notices"""
+    import ngs_barcode_count_amd as pkg
+    c = cases.build_case("del_mismatch_quality", seed=43, n=1200)
+    c["reads"] = [(s, ("@" + q[1:]) if i % 2 == 0 else q) for i, (s, q) in enumerate(c["reads"])]
+    tmp = str(tmp_path)
+    write_inputs(tmp, c)
+    fq = os.path.join(tmp, "reads.fastq")
+    monkeypatch.setenv("BC_INGEST_CHUNK", "32768")
+    plan = pkg.Plan(c["scheme"])
+    for s, i in c["samples"].items():
+        plan.add_sample(s, i)
+    for b, refs in enumerate(c["counted"]):
+        for s in refs:
+            plan.add_counted(b, s, s)
+    kw = c.get("kwargs", {})
+    plan.set_max_errors(kw.get("max_sample"), kw.get("max_barcode"), kw.get("max_constant"))
+    plan.set_min_quality(kw.get("min_quality", 0.0))
+    whole = pkg.Engine(plan, device=0)
+    assert whole.count_fastq(fq) == len(c["reads"])
+    ref_counters, ref_rows = whole.counters(), whole.result_rows()
+    whole.close()
+    for n_shards in (2, 3, 5, 7):
+        eng = pkg.Engine(plan, device=0)
+        totals = [eng.count_fastq(fq, shard=k, n_shards=n_shards) for k in range(n_shards)]
+        assert sum(totals) == len(c["reads"]) and all(t > 0 for t in totals), totals
+        assert eng.counters() == ref_counters and eng.result_rows() == ref_rows
+        eng.close()
+    # a record with a line missing in the first half: the first shard sees lines that do not come in fours
+    lines = open(fq).read().split("\n")
+    del lines[4 * 100 + 2]
+    bad = os.path.join(tmp, "broken.fastq")
+    open(bad, "w").write("\n".join(lines))
+    eng = pkg.Engine(plan, device=0)
+    with pytest.raises(pkg.BarcodeCountError) as err:
+        eng.count_fastq(bad, shard=0, n_shards=2)
+    assert "records of four" in str(err.value)
+    eng.close()

@@ -71,3 +71,29 @@ def test_one_rank_communicator_is_a_plain_finish(tmp_path):
     c2, r2 = eng.finish_all(None, 0)  # no communicator at all
     assert c2 == counters and r2 == rows
     eng.close()
+
+
+def test_rccl_communicator_of_one_rank():
+    """librccl is found and loaded on first use, a unique id is made, a communicator initialised on this device and
+    used (a one-rank job's exchange is the plain finish); the peer-to-peer sends themselves need a second GPU"""
+    import torch
+    import ngs_barcode_count_amd as pkg
+    import workloads
+    ident = pkg.Comm.unique_id()
+    assert len(ident) == 128 and any(ident)
+    comm = pkg.Comm.rccl(ident, 0, 1, 0)
+    assert (comm.rank, comm.world) == (0, 1)
+    comm.barrier()
+    assert comm.sum_u64([5, 7], 0) == [5, 7]
+    w = workloads.make("config3", n_sets=(4, 20, 20, 20))
+    n, R = 10_000, w.read_len
+    seq, qual = w.synth.generate_host(0, n)
+    eng = pkg.Engine(w.plan, device=0)
+    eng.submit_host(seq, qual, R, R)
+    counters = eng.reduce_all(comm, 0)
+    o = workloads.oracle_for(w)
+    o.process_batch(seq, qual, R, R)
+    assert {k: counters[k] for k in o.counters} == o.counters
+    assert eng.result_rows() == o.rows()
+    eng.close()
+    comm.close()
