@@ -183,6 +183,12 @@ int bc_plan_mode(const bc_plan *p);
  * the set into the dense table).  A key is tuple_index * 5^len + base-5 code of the random barcode
  * (A,C,T,G,N = 0..4).  Across GPUs a sum of tables would be wrong: export the
  * keys, exchange them so that every key has one owner, import, then reduce.  Device pointers. */
+/* Plans whose captures kept raw (no conversion file) or whose random barcode do not fit that 64-bit key -- more than 27
+ * bases, or several captures that overflow it together -- count under WIDE keys of bc_engine_key_words() u64 each (word
+ * 0 a fingerprint of the rest, then the captures as bit planes; csrc/bc_long.h): everywhere below a key is then that
+ * many consecutive u64, and a buffer of n keys holds n * bc_engine_key_words() of them.  Such plans run on the
+ * wave-per-read kernel and hand their rows out as text (bc_engine_row_text). */
+uint32_t bc_engine_key_words(const bc_engine *e);
 int bc_engine_key_count(bc_engine *e, uint64_t *n);
 int bc_engine_export_keys(bc_engine *e, void *d_keys, uint64_t capacity, uint64_t *n);
 int bc_engine_import_keys(bc_engine *e, const void *d_keys, uint64_t n, uint64_t *n_new);

@@ -90,6 +90,7 @@ ENGINE_API = {
     "bc_plan_precompile": (_int, [_vp, _u32, _u32, _int, _cp]),  # lives with the engine: it drives the device compiler
     "bc_engine_trace": (_int, [_vp, _vp, _vp]),
     "bc_engine_row_text": (_int, [_vp, _u64, _cp, _sz, _cp, _sz, C.POINTER(C.c_uint64)]),
+    "bc_engine_key_words": (_u32, [_vp]),
     "bc_engine_key_count": (_int, [_vp, C.POINTER(C.c_uint64)]),
     "bc_engine_export_keys": (_int, [_vp, _vp, _u64, C.POINTER(C.c_uint64)]),
     "bc_engine_import_keys": (_int, [_vp, _vp, _u64, C.POINTER(C.c_uint64)]),

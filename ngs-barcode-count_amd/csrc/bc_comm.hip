@@ -81,12 +81,12 @@ __device__ __forceinline__ int dev_key_owner(unsigned long long key, int world) 
   return (int)((x >> 7) % (unsigned long long)world);
 }
 // keys per owner (one cursor add per wavefront and owner)
-__global__ void comm_owner_count_kernel(const unsigned long long* __restrict__ keys, uint64_t n, int world, int fixed_owner,
-                                        unsigned long long* __restrict__ counts) {
+__global__ void comm_owner_count_kernel(const unsigned long long* __restrict__ keys, uint32_t words, uint64_t n, int world,
+                                        int fixed_owner, unsigned long long* __restrict__ counts) {
   const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < n; base += step) {
     const uint64_t i = base + threadIdx.x;
-    const int o = i < n ? (fixed_owner >= 0 ? fixed_owner : dev_key_owner(keys[i], world)) : -1;
+    const int o = i < n ? (fixed_owner >= 0 ? fixed_owner : dev_key_owner(keys[i * words], world)) : -1;
     for (int r = 0; r < world; ++r) {
       const unsigned long long m = __ballot(o == r);
       if (m && __lane_id() == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(&counts[r], (unsigned long long)__popcll(m));
@@ -94,13 +94,14 @@ __global__ void comm_owner_count_kernel(const unsigned long long* __restrict__ k
   }
 }
 // ... and into their owner's range of the output (cursor[r] starts at the range's first slot)
-__global__ void comm_owner_scatter_kernel(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                          uint64_t n, int world, int fixed_owner, unsigned long long* __restrict__ cursor,
+__global__ void comm_owner_scatter_kernel(const unsigned long long* __restrict__ keys, uint32_t words,
+                                          const uint32_t* __restrict__ vals, uint64_t n, int world, int fixed_owner,
+                                          unsigned long long* __restrict__ cursor,
                                           unsigned long long* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
   const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < n; base += step) {
     const uint64_t i = base + threadIdx.x;
-    const unsigned long long k = i < n ? keys[i] : 0ull;
+    const unsigned long long k = i < n ? keys[i * words] : 0ull;
     const int o = i < n ? (fixed_owner >= 0 ? fixed_owner : dev_key_owner(k, world)) : -1;
     for (int r = 0; r < world; ++r) {
       const unsigned long long m = __ballot(o == r);
@@ -112,7 +113,8 @@ __global__ void comm_owner_scatter_kernel(const unsigned long long* __restrict__
               (unsigned long long)(unsigned)__shfl((int)first, (int)leader);
       if (o == r) {
         const unsigned long long p = first + (unsigned long long)__popcll(m & ((1ull << __lane_id()) - 1ull));
-        keys_out[p] = k;
+        keys_out[p * words] = k;
+        for (uint32_t w = 1; w < words; ++w) keys_out[p * words + w] = keys[i * words + w];
         if (vals) vals_out[p] = vals[i];
       }
     }
@@ -208,8 +210,8 @@ struct HipOps {
     if (rc) set_error("exchange: adding the overflow list failed");
     return rc;
   }
-  int partition_keys(const uint64_t* keys, const uint32_t* vals, uint64_t n, int world, int fixed_owner, uint64_t* keys_out,
-                     uint32_t* vals_out, uint64_t* counts) {
+  int partition_keys(const uint64_t* keys, uint32_t words, const uint32_t* vals, uint64_t n, int world, int fixed_owner,
+                     uint64_t* keys_out, uint32_t* vals_out, uint64_t* counts) {
     for (int r = 0; r < world; ++r) counts[r] = 0;
     if (n == 0) return 0;
     unsigned long long* d_cnt = nullptr;
@@ -218,7 +220,7 @@ struct HipOps {
     std::vector<unsigned long long> h((size_t)world, 0);
     if (hipMemsetAsync(d_cnt, 0, (size_t)world * 16, st) != hipSuccess) rc = BC_ERR_HIP;
     if (!rc) {
-      hipLaunchKernelGGL(comm_owner_count_kernel, dim3(grid_of(n)), dim3(256), 0, st, (const unsigned long long*)keys, n, world,
+      hipLaunchKernelGGL(comm_owner_count_kernel, dim3(grid_of(n)), dim3(256), 0, st, (const unsigned long long*)keys, words, n, world,
                          fixed_owner, d_cnt);
       if (hipMemcpyAsync(h.data(), d_cnt, (size_t)world * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
           hipStreamSynchronize(st) != hipSuccess)
@@ -229,8 +231,8 @@ struct HipOps {
       for (int r = 1; r < world; ++r) start[(size_t)r] = start[(size_t)r - 1] + h[(size_t)r - 1];
       if (hipMemcpyAsync(d_cnt + world, start.data(), (size_t)world * 8, hipMemcpyHostToDevice, st) != hipSuccess) rc = BC_ERR_HIP;
       if (!rc) {
-        hipLaunchKernelGGL(comm_owner_scatter_kernel, dim3(grid_of(n)), dim3(256), 0, st, (const unsigned long long*)keys, vals, n,
-                           world, fixed_owner, d_cnt + world, (unsigned long long*)keys_out, vals_out);
+        hipLaunchKernelGGL(comm_owner_scatter_kernel, dim3(grid_of(n)), dim3(256), 0, st, (const unsigned long long*)keys, words, vals,
+                           n, world, fixed_owner, d_cnt + world, (unsigned long long*)keys_out, vals_out);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = BC_ERR_HIP;
       }
     }
@@ -525,7 +527,8 @@ int bc_engine_reduce_all(bc_engine* e, bc_comm* c, int root, uint64_t counters[B
     else
       rc = bc_engine_key_count(e, &n);
     if (rc) return rc;
-    unsigned long long* d_keys = (unsigned long long*)ops.alloc((size_t)(n + 2) * 8);
+    const uint32_t kw = bc_engine_key_words(e);  // u64 words per key: 1, or a plan with wide keys
+    unsigned long long* d_keys = (unsigned long long*)ops.alloc((size_t)(n * kw + 2) * 8);
     uint32_t* d_cnts = with_counts ? (uint32_t*)ops.alloc((size_t)(n + 4) * 4) : nullptr;
     uint64_t* got_k = nullptr;
     uint32_t* got_v = nullptr;
@@ -533,8 +536,8 @@ int bc_engine_reduce_all(bc_engine* e, bc_comm* c, int root, uint64_t counters[B
     if (!d_keys || (with_counts && !d_cnts)) rc = BC_ERR_NOMEM;
     if (!rc && n) rc = with_counts ? bc_engine_export_counts(e, d_keys, d_cnts, n, &n) : bc_engine_export_keys(e, d_keys, n, &n);
     if (!rc)
-      rc = status(exchange_keys(t, ops, (const uint64_t*)d_keys, d_cnts, n, sparse ? root : -1, &got_k, with_counts ? &got_v : nullptr,
-                                &n_in));
+      rc = status(exchange_keys(t, ops, (const uint64_t*)d_keys, kw, d_cnts, n, sparse ? root : -1, &got_k,
+                                with_counts ? &got_v : nullptr, &n_in));
     if (!rc) rc = bc_engine_clear_keys(e);
     if (!rc && n_in) rc = with_counts ? bc_engine_import_counts(e, got_k, got_v, n_in) : bc_engine_import_keys(e, got_k, n_in, &n_new);
     if (d_keys) ops.release(d_keys);

@@ -17,9 +17,11 @@
 //   int sum_u8(const uint8_t* rows, uint32_t n_rows, uint64_t len, uint32_t* out)    out[i] = sum_r rows[r*len + i]
 //   int widen_u8(const uint8_t* src, uint64_t n, uint32_t* dst)                      dst[i] = src[i]
 //   int scatter_add(uint32_t* table, const uint64_t* idx, const uint32_t* val, uint64_t m)   host lists in
-//   int partition_keys(const uint64_t* keys, const uint32_t* vals /*or null*/, uint64_t n, int world, int fixed_owner,
-//                      uint64_t* keys_out, uint32_t* vals_out, uint64_t* counts /*host, world*/)
-//                                                    keys grouped by owner rank (key_owner(), or fixed_owner >= 0)
+//   int partition_keys(const uint64_t* keys, uint32_t words, const uint32_t* vals /*or null*/, uint64_t n, int world,
+//                      int fixed_owner, uint64_t* keys_out, uint32_t* vals_out, uint64_t* counts /*host, world*/)
+//                                                    keys (`words` u64 each; the owner comes from the first word, which
+//                                                    for a wide key is a fingerprint of the rest) grouped by owner rank
+//                                                    (key_owner(), or fixed_owner >= 0)
 //   int sync()                                       everything above has finished
 #pragma once
 #include <algorithm>
@@ -156,26 +158,26 @@ int reduce_tables(Transport& t, Ops& ops, uint32_t* table, uint64_t n, int root)
 }
 
 // Keys (and, when vals != null, a u32 travelling with each) to their owner ranks: by key_owner(), or all of them to
-// `fixed_owner` when that is >= 0.  keys / vals: n entries in the exchange's memory space.  On return *keys_in (and
+// `fixed_owner` when that is >= 0.  keys / vals: n entries in the exchange's memory space; a key is `words` u64.  On return *keys_in (and
 // *vals_in) hold the n_in entries this rank now owns -- allocated here from `ops`, released by the caller.
 template <class Ops>
-int exchange_keys(Transport& t, Ops& ops, const uint64_t* keys, const uint32_t* vals, uint64_t n, int fixed_owner,
+int exchange_keys(Transport& t, Ops& ops, const uint64_t* keys, uint32_t words, const uint32_t* vals, uint64_t n, int fixed_owner,
                   uint64_t** keys_in, uint32_t** vals_in, uint64_t* n_in) {
   const int W = t.world;
   *keys_in = nullptr;
   if (vals_in) *vals_in = nullptr;
   *n_in = 0;
   Scoped<Ops> mem(ops);
-  uint64_t* sorted_k = mem.template get<uint64_t>((size_t)n + 2);
+  uint64_t* sorted_k = mem.template get<uint64_t>((size_t)n * words + 2);
   uint32_t* sorted_v = vals ? mem.template get<uint32_t>((size_t)n + 4) : nullptr;
   if (!sorted_k || (vals && !sorted_v)) return -4;
   std::vector<uint64_t> n_to((size_t)W, 0), n_from((size_t)W, 0);
-  int rc = ops.partition_keys(keys, vals, n, W, fixed_owner, sorted_k, sorted_v, n_to.data());
+  int rc = ops.partition_keys(keys, words, vals, n, W, fixed_owner, sorted_k, sorted_v, n_to.data());
   if (rc) return rc;
   if ((rc = t.exchange_counts(n_to.data(), n_from.data()))) return rc;
   uint64_t total = 0;
   for (uint64_t v : n_from) total += v;
-  uint64_t* got_k = (uint64_t*)ops.alloc((size_t)(total + 2) * 8);
+  uint64_t* got_k = (uint64_t*)ops.alloc((size_t)(total * words + 2) * 8);
   uint32_t* got_v = vals ? (uint32_t*)ops.alloc((size_t)(total + 4) * 4) : nullptr;
   if (!got_k || (vals && !got_v)) {
     if (got_k) ops.release(got_k);
@@ -184,8 +186,8 @@ int exchange_keys(Transport& t, Ops& ops, const uint64_t* keys, const uint32_t* 
   }
   std::vector<uint64_t> sb((size_t)W), rb((size_t)W);
   for (int r = 0; r < W; ++r) {
-    sb[(size_t)r] = n_to[(size_t)r] * 8;
-    rb[(size_t)r] = n_from[(size_t)r] * 8;
+    sb[(size_t)r] = n_to[(size_t)r] * 8 * words;
+    rb[(size_t)r] = n_from[(size_t)r] * 8 * words;
   }
   rc = ops.sync();
   if (!rc) rc = t.all_to_all_v(sorted_k, sb.data(), got_k, rb.data());

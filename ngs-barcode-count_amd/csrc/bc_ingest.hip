@@ -473,7 +473,7 @@ struct Source {
     if (pos >= size) return 0;
     cap = (size_t)std::min<unsigned long long>(cap, size - pos);
     // page cache -> pinned memory, one slice per thread
-    const size_t slice = ((cap / threads) + 4095) & ~(size_t)4095;
+    const size_t slice = (((cap + threads - 1) / threads) + 4095) & ~(size_t)4095;  // (never 0: cap may be a few bytes)
     std::vector<long> got(threads, 0);
     std::vector<std::thread> team;
     auto work = [&](unsigned t) {
@@ -722,7 +722,7 @@ static int fastq_count_impl(bc_engine* e, const char* fastq_path, uint32_t shard
   });
 
   uint64_t total = 0, lines_after_last_record = 0;
-  bool last_byte_newline = true, any_bytes = false, appended_newline = false;
+  bool last_byte_newline = true, any_bytes = false, appended_newline = false, gz_last_char_dropped = false;
   bool test = shard == 0;  // (the file's first record is the first shard's)
   int pending = -1;  // chunk framed but not yet submitted
   for (int i = 0;; ++i) {
@@ -766,6 +766,13 @@ static int fastq_count_impl(bc_engine* e, const char* fastq_path, uint32_t shard
         if (!gz) {  // lines() hands the last line over without its newline (input.rs:44): framing-wise it has one
           s.pin[s.len++] = '\n';
           appended_newline = true;
+        } else {
+          // read_line hands the unterminated last line over as it is, and post() pops the record's last character
+          // whatever it is (input.rs:137): when that line is a record's fourth, the record is scored with a quality
+          // line one character short.  Turning the character into the missing newline is exactly that; when the line is
+          // a record's first, second or third, no record comes of it and only the line count matters.
+          s.pin[s.len - 1] = '\n';
+          gz_last_char_dropped = true;
         }
       }
       rc = in.frame(i % kSlots, i > 0 ? &in.slot[(i - 1) % kSlots] : nullptr);
@@ -814,14 +821,9 @@ static int fastq_count_impl(bc_engine* e, const char* fastq_path, uint32_t shard
   {
     // lines the reference's reader would have been handed after the last whole record
     size_t seen = (size_t)lines_after_last_record;
-    if (gz && !last_byte_newline) seen += 1;  // read_line returns the unterminated last line too
-    if (gz && seen == 4) {
-      // (only reachable without a final newline) post() pops the record's last character unconditionally
-      // (input.rs:137): here that is the last quality character, so the reference scores a quality line one short
-      set_error("gz input without a final newline: the reference drops the last quality character "
-                "(input.rs:137); not supported by the engine");
-      return finish(BC_ERR_UNSUPPORTED);
-    }
+    // (gz without a final newline: the unterminated last line was given its newline above, so it is among the lines
+    // the device counted)
+    (void)gz_last_char_dropped;
     (void)appended_newline;
     if (!last_shard && !(gz && shard == 0) && seen != 0) {
       // a shard that does not end the file ends on a record boundary; lines left over mean the file's lines do not

@@ -619,7 +619,38 @@ bool bc_plan::lower_long(LongHost& out) const {
   out.ref_off.assign(order.size(), {});
   out.n_samples = sample_barcode ? (uint32_t)samples.size() : 1u;
   P.discard_counts = (!sample_barcode && samples.size() > 0 && !random_barcode) ? 1u : 0u;
+  // Do the captures fit the one 64-bit mixed-radix key (index of a known set, base-5 code of a capture kept raw, base-5
+  // code of the random barcode)?  If not -- a raw capture or a random barcode above 27 bases, or several that overflow
+  // together -- the plan counts under wide keys (bc_long.h).
+  bool wide = false;
+  {
+    // (the very tests lower() makes before it gives a plan to the lane-per-read kernel: both must agree on what a
+    // 64-bit key can hold, since an engine may run the two kernels side by side -- reads above 320 bases)
+    unsigned __int128 space = 1;
+    const unsigned __int128 limit = (unsigned __int128)1 << 63;
+    for (const Pending& pd : order) {
+      if (pd.set->size() == 0) {
+        if (pd.g->len > 27) wide = true;
+        for (uint32_t k = 0; k < pd.g->len && space < limit; ++k) space *= 5;
+      } else {
+        space *= pd.set->size();
+      }
+      if (space >= limit) wide = true;
+    }
+    if (random_barcode && !wide)
+      for (const auto& g : groups) {
+        if (g.type != kGroupRandom) continue;
+        if (g.len > 27) {
+          wide = true;
+          continue;
+        }
+        unsigned __int128 rs = 1;
+        for (uint32_t k = 0; k < g.len; ++k) rs *= 5;
+        if (rs * space >= ((unsigned __int128)1 << 64) - 1) wide = true;
+      }
+  }
   unsigned __int128 entries = 1;
+  uint32_t key_bits = 0;
   for (int i = (int)order.size() - 1; i >= 0; --i) {
     const Pending& pd = order[i];
     LongGroup& G = P.groups[i];
@@ -628,16 +659,14 @@ bool bc_plan::lower_long(LongHost& out) const {
     G.len = pd.g->len;
     G.n_refs = (uint32_t)pd.set->size();
     G.max_err = pd.max_err;
-    G.table_stride = (uint64_t)entries;
+    G.table_stride = wide ? 0 : (uint64_t)entries;
+    G.key_bit = 0;
     if (G.n_refs == 0) {
-      if (G.len > 27) {
-        set_error("unsupported plan: barcodes without a conversion file must be at most 27 bases");
-        return false;
-      }
       P.sparse = 1;
-      for (uint32_t k = 0; k < G.len; ++k) entries *= 5;
+      if (!wide)
+        for (uint32_t k = 0; k < G.len; ++k) entries *= 5;
     } else {
-      entries *= G.n_refs;
+      if (!wide) entries *= G.n_refs;
       auto& off = out.ref_off[i];
       auto& text = out.ref_text[i];
       for (const std::string& s : pd.set->seqs) {
@@ -646,33 +675,50 @@ bool bc_plan::lower_long(LongHost& out) const {
       }
       off.push_back((uint32_t)text.size());
     }
-    if (entries >= ((unsigned __int128)1 << 63)) {
-      set_error("unsupported plan: the (sample, barcode tuple) space does not fit a 64-bit key");
-      return false;
-    }
   }
-  if (!P.sparse && entries > ((unsigned __int128)1 << 40)) {
+  if (!P.sparse && !wide && entries > ((unsigned __int128)1 << 40)) {
     set_error("unsupported plan: dense counter table above 2^40 entries");
     return false;
   }
-  out.table_entries = (uint64_t)entries;
+  P.wide = wide ? 1u : 0u;
+  P.key_words = 1;
+  P.rnd_bit = 0;
+  if (wide) {
+    // payload layout, group after group from bit 0: 32 bits of reference index, or the capture's three bit planes
+    P.sparse = 1;  // counts live in a key map (rows are read as text, bc_engine_row_text), whatever the sets are
+    for (uint32_t i = 0; i < P.n_groups; ++i) {
+      P.groups[i].key_bit = key_bits;
+      key_bits += P.groups[i].n_refs ? 32u : 3u * P.groups[i].len;
+    }
+  }
+  out.table_entries = wide ? 0 : (uint64_t)entries;
   if (random_barcode) {
     for (const auto& g : groups) {
       if (g.type != kGroupRandom) continue;
-      if (g.len == 0 || g.len > 27) {
-        set_error("unsupported scheme: random barcodes must be 1..27 bases");
-        return false;
-      }
-      unsigned __int128 space = 1;
-      for (uint32_t i = 0; i < g.len; ++i) space *= 5;
-      if (space * entries >= ((unsigned __int128)1 << 64) - 1) {
-        set_error("unsupported plan: (barcode tuple, random barcode) does not fit a 64-bit key");
+      if (g.len == 0) {
+        set_error("unsupported scheme: empty random barcode");
         return false;
       }
       P.has_random = 1;
       P.rnd_off = g.off;
       P.rnd_len = g.len;
-      P.rspace = (uint64_t)space;
+      if (wide) {
+        P.rnd_bit = key_bits;
+        key_bits += 3u * g.len;
+        P.rspace = 0;
+      } else {
+        unsigned __int128 space = 1;
+        for (uint32_t i = 0; i < g.len; ++i) space *= 5;
+        P.rspace = (uint64_t)space;
+      }
+    }
+  }
+  if (wide) {
+    P.key_words = 1u + (key_bits + 63u) / 64u;
+    if (P.key_words > (uint32_t)kMaxKeyWords) {
+      set_error("unsupported plan: the captures kept raw (no conversion file) and the random barcode take " +
+                std::to_string(key_bits) + " key bits; the engine's widest key holds " + std::to_string(64 * (kMaxKeyWords - 1)));
+      return false;
     }
   }
   return true;

@@ -61,16 +61,16 @@ struct HostOps {
     for (uint64_t k = 0; k < m; ++k) table[idx[k]] += val[k];
     return 0;
   }
-  int partition_keys(const uint64_t* keys, const uint32_t* vals, uint64_t n, int world, int fixed_owner, uint64_t* ko, uint32_t* vo,
-                     uint64_t* counts) {
+  int partition_keys(const uint64_t* keys, uint32_t words, const uint32_t* vals, uint64_t n, int world, int fixed_owner, uint64_t* ko,
+                     uint32_t* vo, uint64_t* counts) {
     std::vector<uint64_t> at((size_t)world, 0);
     for (int r = 0; r < world; ++r) counts[r] = 0;
     auto own = [&](uint64_t k) { return fixed_owner >= 0 ? fixed_owner : bc::key_owner(k, world); };
-    for (uint64_t i = 0; i < n; ++i) counts[own(keys[i])]++;
+    for (uint64_t i = 0; i < n; ++i) counts[own(keys[i * words])]++;
     for (int r = 1; r < world; ++r) at[(size_t)r] = at[(size_t)r - 1] + counts[r - 1];
     for (uint64_t i = 0; i < n; ++i) {
-      const uint64_t p = at[(size_t)own(keys[i])]++;
-      ko[p] = keys[i];
+      const uint64_t p = at[(size_t)own(keys[i * words])]++;
+      for (uint32_t w = 0; w < words; ++w) ko[p * words + w] = keys[i * words + w];
       if (vals) vo[p] = vals[i];
     }
     return 0;
@@ -119,19 +119,26 @@ int main(int argc, char** argv) {
       fclose(f);
     }
   } else if (kind == "keys") {
-    std::vector<uint64_t> keys(n);
+    // (keys of `words` u64: word 0 as before, the further words derived from it -- a wide key travels whole)
+    const uint32_t words = argc > 9 ? (uint32_t)atoi(argv[9]) : 1u;
+    std::vector<uint64_t> keys(n * words);
     std::vector<uint32_t> vals(n);
     for (uint64_t i = 0; i < n; ++i) {
-      keys[i] = mix(seed + (i * 3 + (uint64_t)rank) % (2 * n + 1));  // overlapping between ranks
+      keys[i * words] = mix(seed + (i * 3 + (uint64_t)rank) % (2 * n + 1));  // overlapping between ranks
+      for (uint32_t w = 1; w < words; ++w) keys[i * words + w] = mix(keys[i * words] + w);
       vals[i] = (uint32_t)(rank * 1000 + i % 7);
     }
     uint64_t* gk = nullptr;
     uint32_t* gv = nullptr;
     uint64_t n_in = 0;
-    rc = bc::exchange_keys(t, ops, keys.data(), vals.data(), n, root, &gk, &gv, &n_in);
+    rc = bc::exchange_keys(t, ops, keys.data(), words, vals.data(), n, root, &gk, &gv, &n_in);
     if (!rc) {
       std::vector<std::pair<uint64_t, uint32_t>> got(n_in);
-      for (uint64_t i = 0; i < n_in; ++i) got[i] = {gk[i], gv[i]};
+      for (uint64_t i = 0; i < n_in; ++i) {
+        got[i] = {gk[i * words], gv[i]};
+        for (uint32_t w = 1; w < words; ++w)
+          if (gk[i * words + w] != mix(gk[i * words] + w)) rc = 9;  // a key arrived torn
+      }
       std::sort(got.begin(), got.end());
       FILE* f = fopen((out + "." + std::to_string(rank)).c_str(), "wb");
       for (auto& p : got) {

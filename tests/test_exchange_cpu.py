@@ -85,12 +85,15 @@ def _key_owner(keys, world):
     return ((x >> np.uint64(7)) % np.uint64(world)).astype(np.int64)
 
 
-@pytest.mark.parametrize("world,n,root", [(2, 5000, -1), (3, 4001, -1), (3, 1000, 1), (4, 0, -1)])
-def test_keys_reach_their_owner(tmp_path, world, n, root):
+@pytest.mark.parametrize("world,n,root,words", [(2, 5000, -1, 1), (3, 4001, -1, 1), (3, 1000, 1, 1), (4, 0, -1, 1),
+                                                (3, 3000, -1, 4), (2, 800, 0, 3)])
+def test_keys_reach_their_owner(tmp_path, world, n, root, words):
     """hashed ownership (random-barcode plans: duplicates across ranks meet on one rank) and everything-to-the-root
     (raw-key plans); the u32 travelling with each key stays with it"""
     out = tmp_path / "keys"
-    _run_ranks(tmp_path, world, lambda r: ["keys", str(n), "7", str(root), str(out)])
+    # (words > 1: keys several u64 wide, as the plans with long raw captures have them -- every key must arrive whole,
+    # which the ranks check themselves)
+    _run_ranks(tmp_path, world, lambda r: ["keys", str(n), "7", str(root), str(out), str(words)])
     sent = []
     for r in range(world):
         i = np.arange(n, dtype=np.uint64)

@@ -329,3 +329,30 @@ def test_fastq_shards_tile_the_file(tmp_path, monkeypatch):
         eng.count_fastq(bad, shard=0, n_shards=2)
     assert "records of four" in str(err.value)
     eng.close()
+
+
+def test_gz_without_a_final_newline(tmp_path):
+    """a .gz whose last line has no newline used to be refused.  The reference's read_line hands that line
+    over as it is and post() pops the record's last character whatever it is (input.rs:137): the last record is scored
+    with a quality line one character short -- here a quality line whose one low score sits in that last character, so
+    the verdict changes with it.  A stream that stops inside a record's second line only adds to the total."""
+    from test_gpu_parity import make_plan
+    c = cases.build_case("del_mismatch_quality", seed=61, n=500)
+    plan = make_plan(c)
+    reads = list(c["reads"])
+    # the last read: a clean construct whose last scored barcode base is the read's last base, quality 2 only there
+    s_last, q_last = next((s, q) for s, q in reads if parity.oracle_for(c).process(s, q) == "matched")
+    reads[-1] = (s_last, q_last)
+    text = "".join("@r%d\n%s\n+\n%s\n" % (i, s, q) for i, (s, q) in enumerate(reads))
+    for variant in ("fourth_line", "second_line"):
+        body = text[:-1] if variant == "fourth_line" else text + "@tail\nACGTACGT"
+        fq = os.path.join(str(tmp_path), variant + ".fastq.gz")
+        with gzip.open(fq, "wb") as f:
+            f.write(body.encode())
+        o = parity.oracle_for(c)
+        for i, (s, q) in enumerate(reads):
+            o.process(s, q[:-1] if (variant == "fourth_line" and i == len(reads) - 1) else q)
+        total, got, rows = _count_file(plan, fq)
+        assert total == len(reads) + 1, (variant, total)  # fourth_line: the gz path's extra read("") (input.rs:69-73); second_line: the partial record
+        assert got["total_reads"] == len(reads)
+        assert {k: got[k] for k in o.counters} == o.counters and rows == o.rows(), variant

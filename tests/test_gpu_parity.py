@@ -362,8 +362,8 @@ def test_errors_are_loud():
     pkg = _pkg()
     with pytest.raises(pkg.BarcodeCountError):  # a token mixing 'N' and 'n': the reference's regex and format_string differ in length
         pkg.Engine(pkg.Plan("[8]ACGTNnN{8}"), device=0)
-    with pytest.raises(pkg.BarcodeCountError):  # raw barcodes that do not fit a 64-bit key
-        pkg.Engine(pkg.Plan("[20]ACGT{20}TT{20}"), device=0)
+    with pytest.raises(pkg.BarcodeCountError):  # raw captures beyond even the widest key (448 payload bits)
+        pkg.Engine(pkg.Plan("[60]ACGT{60}TT{60}"), device=0)
     p = make_plan(dict(scheme="ACGTACGT{8}TTGG", counted=[["ACGTACGT"]], kwargs=dict(min_quality=10.0)))
     e = pkg.Engine(p, device=0)
     import torch
