@@ -141,6 +141,14 @@ def load(path=None):
     if not os.path.exists(p):
         raise RuntimeError("HIP engine library not built: %s (run `python -c 'import __graft_entry__ as g; "
                            "g.build()'` or `make -C %s`)" % (p, CSRC_DIR))
+    # PyTorch-ROCm ships its own copy of the HIP runtime; whichever copy a process loads SECOND finds no GPU.  This
+    # library links the system's (/opt/rocm): when torch is installed but not imported yet, import it first, so that the
+    # one runtime both use is torch's.  (A process that never imports torch is unaffected; BC_NO_TORCH_PRELOAD=1 skips.)
+    import sys
+    if "torch" not in sys.modules and not os.environ.get("BC_NO_TORCH_PRELOAD"):
+        import importlib.util
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
     lib = C.CDLL(p)
     declare(lib, PLAN_API)
     declare(lib, ENGINE_API)

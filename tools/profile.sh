@@ -11,7 +11,9 @@ TAG=$1
 CFG=${2:-config3}
 OUT=$R/gpurun_out/profile_$TAG
 mkdir -p $OUT
-ARGS="--config $CFG --no-cpu --no-extra --steps 5 --warmup 1"
+# the driver's own step / warm-up counts (python3 bench.py --gpus 1 --steps 20 --warmup 5), so that the profiled run is the
+# judged run; STEPS / WARMUP override
+ARGS="--config $CFG --no-cpu --no-extra --steps ${STEPS:-20} --warmup ${WARMUP:-5}"
 python3 $R/bench.py $ARGS > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
 export BC_JIT=cached
 cd /tmp
@@ -22,7 +24,7 @@ for c in FETCH_SIZE WRITE_SIZE \
          "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE" \
          "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS TCC_HIT_sum TCC_MISS_sum"; do
   n=$(echo $c | cut -d' ' -f1)
-  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$n -- python3 $R/bench.py --config $CFG --no-cpu --no-extra --steps 2 --warmup 1 > /dev/null 2>> $OUT/bench.err
+  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$n -- python3 $R/bench.py --config $CFG --no-cpu --no-extra --steps 3 --warmup 1 > /dev/null 2>> $OUT/bench.err
 done
 python3 - <<PY
 import csv, glob, collections, json
