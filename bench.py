@@ -57,6 +57,10 @@ def parse_args(argv=None):
                     help="reads of the CPU baseline's independent-context leg (the reference-structure leg takes the first 1.5 M)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the legs beside the headline (finish, end-to-end, ingest, the other configs)")
+    ap.add_argument("--selftest-one-gpu", action="store_true",
+                    help="TEST ONLY (tests/test_gpu_multirank.py): the N > 1 path with every rank on device 0 -- the box has one "
+                         "GPU --, torch.distributed on gloo and the engines' exchange over the message-file transport "
+                         "instead of RCCL; prints a line marked invalid")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="TEST ONLY (tests/test_bench_launcher.py): the rank plumbing on gloo with the host emulation of "
                          "the lane code; prints a line marked invalid, measures nothing")
@@ -316,7 +320,8 @@ class Run:
         self._barrier()
         elapsed = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([elapsed, t_steps, reduce_ms], dtype=torch.float64, device=dev)
+            t = torch.tensor([elapsed, t_steps, reduce_ms], dtype=torch.float64,
+                             device=dev if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed, t_steps, reduce_ms = t.tolist()
 
@@ -519,10 +524,13 @@ def main():
     import torch
     import torch.distributed as dist
 
+    one_gpu = args.selftest_one_gpu  # TEST ONLY: all ranks on device 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if one_gpu else "nccl", rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py needs a GPU: the engine has no CPU path"
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -531,11 +539,17 @@ def main():
         # the engine library's own communicator (bc_comm over RCCL): rank 0 makes the id, torch.distributed -- which the
         # timing contract needs anyway for its barrier and its max over ranks -- carries it to the others
         import ngs_barcode_count_amd as pkg
-        ident = torch.zeros(128, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            ident.copy_(torch.frombuffer(bytearray(pkg.Comm.unique_id()), dtype=torch.uint8))
-        dist.broadcast(ident, src=0)
-        comm = pkg.Comm.rccl(bytes(ident.cpu().numpy().tobytes()), rank, world, local)
+        if one_gpu:
+            import tempfile
+            box = [tempfile.mkdtemp(prefix="bc_bench_comm_") if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            comm = pkg.Comm.host(box[0], rank, world)
+        else:
+            ident = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                ident.copy_(torch.frombuffer(bytearray(pkg.Comm.unique_id()), dtype=torch.uint8))
+            dist.broadcast(ident, src=0)
+            comm = pkg.Comm.rccl(bytes(ident.cpu().numpy().tobytes()), rank, world, local)
     n = args.reads or DEFAULT_READS[args.config]
     run = Run(args.config, n, args.steps, args.warmup, world, rank, local, dev, comm)
     res = run.measure()
@@ -565,6 +579,7 @@ def main():
                                   "(bc_engine_reduce_all: all-to-all sum of the counter tables, RCCL over xGMI)" % world},
         "roofline": res["roofline"],
         "outcomes": res["outcomes"],
+        **({"valid": False, "selftest": "all ranks on one GPU, message-file exchange: NOT a measurement"} if args.selftest_one_gpu else {}),
         "reduce_ms": res["reduce_ms"],
         "reset_ms": res["reset_ms"],
         "reset_in_region_ms": res["reset_in_region_ms"],
@@ -580,7 +595,7 @@ def main():
             out["roofline"]["frac_of_box_copy"] = out["roofline"]["achieved"] / box["copy_GBps"] if box.get("copy_GBps") else None
         except Exception as err:  # noqa: BLE001 -- nothing beside the timed region may cost the line
             out["box"] = {"error": repr(err)}
-    if not args.no_cpu:
+    if not args.no_cpu and world == 1:  # (rank 0 at N = 1 only: the contract's baseline leg)
         try:
             out["cpu_baseline"] = cpu_baselines(run.w, min(args.cpu_sample, n), max(2, min(os.cpu_count() or 2, 16)))
         except Exception as err:  # noqa: BLE001

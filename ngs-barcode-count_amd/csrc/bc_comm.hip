@@ -482,16 +482,14 @@ static int bind_stream(bc_engine* e, bc_comm* c, HipOps& ops) {
 
 int bc_comm_barrier(bc_comm* c) {
   if (!c) return BC_OK;
-  if (c->rccl_t && !c->rccl_t->st) {
-    // (no exchange has run yet: the NULL stream of the communicator's device will do)
-    HIPC(hipSetDevice(c->device));
-  }
-  return c->t->barrier();
+  if (c->rccl_t) HIPC(hipSetDevice(c->device));  // (before any exchange the communicator works on that device's NULL stream)
+  const int rc = c->t->barrier();
+  return rc > 0 ? BC_ERR_HIP : rc;
 }
 
 int bc_comm_sum_u64(bc_comm* c, uint64_t* vals, int n, int root) {
   if (!c || c->t->world <= 1) return BC_OK;
-  if (c->rccl_t && !c->rccl_t->st) HIPC(hipSetDevice(c->device));
+  if (c->rccl_t) HIPC(hipSetDevice(c->device));
   const int rc = c->t->reduce_sum_u64(vals, n, root);
   return rc > 0 ? BC_ERR_HIP : rc;
 }

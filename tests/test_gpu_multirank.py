@@ -97,3 +97,35 @@ def test_rccl_communicator_of_one_rank():
     assert eng.result_rows() == o.rows()
     eng.close()
     comm.close()
+
+
+@pytest.mark.parametrize("config,reads", [("config3", 1_000_000), ("config4", 400_000), ("config5", 1_000_000)])
+def test_bench_n_ranks_path_on_one_gpu(config, reads):
+    """bench.py's N > 1 code path end to end (launcher, one engine per rank, the ABI's end-of-run exchange inside the
+    timed region, counters merged on rank 0) with both ranks on this box's one GPU: torch.distributed on gloo, the
+    engines' exchange over message files.  What a multi-GPU node adds to this is RCCL in place of the files."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-one-gpu", "--config", config,
+                        "--reads", str(reads), "--steps", "3", "--warmup", "1", "--no-extra", "--no-cpu"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["valid"] is False
+    assert line["reduce_ms"] > 0
+    out = line["outcomes"]
+    assert out["total_reads"] == 2 * 3 * reads
+    assert sum(out[k] for k in ("matched", "constant_region", "sample_barcode", "barcode", "duplicates", "low_quality")) == out["total_reads"]
+    if config == "config4":
+        # (a step is a job of its own there -- the key set is cleared every step -- and two ranks cut the read stream
+        # into other steps than one rank does: only the exchange itself can be checked, in test_ranks_on_one_gpu_...)
+        assert out["duplicates"] > reads // 4
+        return
+    # the same reads through ONE rank give the same outcome counters
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", config, "--reads", str(2 * reads),
+                          "--steps", "3", "--warmup", "1", "--no-extra", "--no-cpu"], env=env, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    ref = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])["outcomes"]
+    assert out == ref
