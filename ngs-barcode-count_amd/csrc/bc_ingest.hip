@@ -388,9 +388,11 @@ struct Ingest {
     HIP_TRY(hipMemcpyAsync(s.stats, s.d_stats, sizeof(ChunkStats), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(s.framed, st));
     s_text[b] = text;
+    s_text_len[b] = len;
     return BC_OK;
   }
   const uint8_t* s_text[kSlots] = {nullptr, nullptr, nullptr};
+  unsigned long long s_text_len[kSlots] = {0, 0, 0};  // bytes of the framed text behind s_text
 
   // the framed chunk of slot b -> batches for the engine
   int submit(int b, uint64_t* n_rec_out) {
@@ -725,6 +727,7 @@ static int fastq_count_impl(bc_engine* e, const char* fastq_path, uint32_t shard
   bool last_byte_newline = true, any_bytes = false, appended_newline = false, gz_last_char_dropped = false;
   bool test = shard == 0;  // (the file's first record is the first shard's)
   int pending = -1;  // chunk framed but not yet submitted
+  int last_counted_slot = -1;  // slot of the last chunk whose records were counted (its text is still on the device)
   for (int i = 0;; ++i) {
     {
       std::unique_lock<std::mutex> lk(mu);
@@ -788,6 +791,7 @@ static int fastq_count_impl(bc_engine* e, const char* fastq_path, uint32_t shard
       {
         const ChunkStats& cs = *in.slot[pending % kSlots].stats;
         lines_after_last_record = cs.n_lines - 4 * cs.n_rec;
+        last_counted_slot = pending % kSlots;
       }
       pending = -1;
       std::lock_guard<std::mutex> lk(mu);
@@ -804,6 +808,7 @@ static int fastq_count_impl(bc_engine* e, const char* fastq_path, uint32_t shard
         if (progress && n_rec) progress(total - total % 10000, user);  // the reference prints every 10,000 reads (input.rs:54-57)
         const ChunkStats& cs = *in.slot[pending % kSlots].stats;
         lines_after_last_record = cs.n_lines - 4 * cs.n_rec;
+        last_counted_slot = pending % kSlots;
       }
       break;
     }
@@ -831,6 +836,49 @@ static int fastq_count_impl(bc_engine* e, const char* fastq_path, uint32_t shard
       // it differently from here on
       set_error("the lines of " + path + " do not come in records of four: run it on one GPU");
       return finish(BC_ERR_INVALID);
+    }
+    if (gz && seen == 3 && last_counted_slot >= 0) {
+      // The gz loop hands read() one more, empty line at the end of the stream (input.rs:69-73).  After three lines of
+      // a record that makes "line 4": the reference posts the partial record -- header, sequence, '+' line and an EMPTY
+      // quality line (post() pops the last character, unpack() fills what lines there are: parse.rs:236-267) -- and its
+      // workers score it like any other read (an empty quality line passes the quality filter: nothing is zipped,
+      // parse.rs:340-345).  Here: the record's second line, fetched back from the device text, goes through the engine
+      // as one read with a quality line of length 0.
+      const Slot& ls = in.slot[last_counted_slot];
+      const unsigned long long from = ls.stats->end_pos, upto = in.s_text_len[last_counted_slot];
+      std::vector<char> tail((size_t)(upto > from ? upto - from : 0));
+      if (!tail.empty() && hipMemcpy(tail.data(), in.s_text[last_counted_slot] + from, tail.size(), hipMemcpyDeviceToHost) != hipSuccess) {
+        set_error("bc_fastq_count: reading the stream's last lines back failed");
+        return finish(BC_ERR_HIP);
+      }
+      const char* l1 = (const char*)memchr(tail.data(), '\n', tail.size());
+      const char* l2 = l1 ? (const char*)memchr(l1 + 1, '\n', tail.size() - (size_t)(l1 + 1 - tail.data())) : nullptr;
+      if (l1 && l2) {
+        const size_t n = (size_t)(l2 - (l1 + 1));
+        if (n > 65535) {
+          set_error("a FASTQ line is longer than 65535 bytes (not supported by the engine)");
+          return finish(BC_ERR_UNSUPPORTED);
+        }
+        const uint32_t one_stride = std::max<uint32_t>(16u, (uint32_t)((n + 15) & ~(size_t)15));
+        uint8_t* d_one = nullptr;
+        if (hipMalloc((void**)&d_one, (size_t)one_stride * 2 + 32) != hipSuccess) {
+          (void)hipGetLastError();
+          set_error("bc_fastq_count: out of device memory");
+          return finish(BC_ERR_NOMEM);
+        }
+        std::vector<uint8_t> host((size_t)one_stride * 2 + 32, (uint8_t)'\n');
+        memcpy(host.data(), l1 + 1, n);
+        const uint16_t len16 = (uint16_t)n, qlen16 = 0;
+        memcpy(host.data() + 2 * (size_t)one_stride, &len16, 2);
+        memcpy(host.data() + 2 * (size_t)one_stride + 16, &qlen16, 2);
+        int rc1 = hipMemcpy(d_one, host.data(), host.size(), hipMemcpyHostToDevice) == hipSuccess ? BC_OK : BC_ERR_HIP;
+        if (rc1 == BC_OK)
+          rc1 = bc_engine_submit_device_q(e, d_one, d_one + one_stride, d_one + 2 * (size_t)one_stride, d_one + 2 * (size_t)one_stride + 16,
+                                          one_stride, 1);
+        if (rc1 == BC_OK) rc1 = bc_engine_sync(e);
+        (void)hipFree(d_one);
+        if (rc1 != BC_OK) return finish(rc1);
+      }
     }
     if (seen > 0 && seen < 4) total += 1;  // a trailing partial record is counted when its first line is seen (input.rs:128-130)
     if (gz) {

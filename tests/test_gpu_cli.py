@@ -344,15 +344,21 @@ def test_gz_without_a_final_newline(tmp_path):
     s_last, q_last = next((s, q) for s, q in reads if parity.oracle_for(c).process(s, q) == "matched")
     reads[-1] = (s_last, q_last)
     text = "".join("@r%d\n%s\n+\n%s\n" % (i, s, q) for i, (s, q) in enumerate(reads))
-    for variant in ("fourth_line", "second_line"):
-        body = text[:-1] if variant == "fourth_line" else text + "@tail\nACGTACGT"
+    for variant in ("fourth_line", "second_line", "third_line", "third_line_open"):
+        body = {"fourth_line": text[:-1], "second_line": text + "@tail\nACGTACGT",
+                # three lines into a record: the gz loop's extra read("") lands on "line 4" and the reference posts the
+                # partial record with an EMPTY quality line (input.rs:69-73, 137; parse.rs:258-265) -- scored like any read
+                "third_line": text + "@tail\n" + s_last + "\n+\n", "third_line_open": text + "@tail\n" + s_last + "\n+"}[variant]
         fq = os.path.join(str(tmp_path), variant + ".fastq.gz")
         with gzip.open(fq, "wb") as f:
             f.write(body.encode())
         o = parity.oracle_for(c)
         for i, (s, q) in enumerate(reads):
             o.process(s, q[:-1] if (variant == "fourth_line" and i == len(reads) - 1) else q)
+        extra = 1 if variant.startswith("third_line") else 0
+        if extra:
+            assert o.process(s_last, "") == "matched"  # an empty quality line passes the filter
         total, got, rows = _count_file(plan, fq)
-        assert total == len(reads) + 1, (variant, total)  # fourth_line: the gz path's extra read("") (input.rs:69-73); second_line: the partial record
-        assert got["total_reads"] == len(reads)
+        assert total == len(reads) + 1, (variant, total)  # fourth_line: the gz path's extra read("") (input.rs:69-73); else: the partial record
+        assert got["total_reads"] == len(reads) + extra
         assert {k: got[k] for k in o.counters} == o.counters and rows == o.rows(), variant
