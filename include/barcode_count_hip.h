@@ -319,6 +319,9 @@ int bc_fastq_count(bc_engine *e, const char *fastq_path, uint64_t *total_reads, 
  * in the middle: shard 0 reads all of it, the others nothing. */
 int bc_fastq_count_shard(bc_engine *e, const char *fastq_path, uint32_t shard, uint32_t n_shards, uint64_t *total_reads,
                          bc_progress_fn progress, void *user);
+/* where a shard that nominally begins at byte `offset` of a plain FASTQ file really begins: the first record start at
+ * or after it (the file's size when there is none).  Host logic only: no engine, no GPU. */
+int bc_fastq_record_start(const char *fastq_path, uint64_t offset, uint64_t *start);
 
 /* ---- synthetic workloads (bench + full-size parity) -------------------------------------- */
 

@@ -112,6 +112,7 @@ ENGINE_API = {
     "bc_fix_error": (C.c_int64, [_cp, C.POINTER(_cp), _u64, C.c_uint16, _int]),
     "bc_fastq_count": (_int, [_vp, _cp, C.POINTER(C.c_uint64), _vp, _vp]),
     "bc_fastq_count_shard": (_int, [_vp, _cp, _u32, _u32, C.POINTER(C.c_uint64), _vp, _vp]),
+    "bc_fastq_record_start": (_int, [_cp, _u64, C.POINTER(C.c_uint64)]),
     "bc_comm_sum_u64": (_int, [_vp, C.POINTER(C.c_uint64), _int, _int]),
     "bc_synth_create": (_vp, [_vp, C.POINTER(SynthParams)]),
     "bc_synth_destroy": (None, [_vp]),

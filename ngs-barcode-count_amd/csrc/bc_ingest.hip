@@ -564,6 +564,25 @@ long long record_start_at_or_after(int fd, unsigned long long off, unsigned long
 static int fastq_count_impl(bc_engine* e, const char* fastq_path, uint32_t shard, uint32_t n_shards, uint64_t* total_reads,
                             bc_progress_fn progress, void* user);
 
+// where bc_fastq_count_shard would start a shard that nominally begins at byte `offset` (host logic only, no GPU)
+extern "C" int bc_fastq_record_start(const char* fastq_path, uint64_t offset, uint64_t* start) {
+  *start = 0;
+  const int fd = open(fastq_path ? fastq_path : "", O_RDONLY);
+  if (fd < 0) {
+    set_error(std::string("Failed to open file: ") + (fastq_path ? fastq_path : ""));
+    return BC_ERR_INVALID;
+  }
+  const off_t end = lseek(fd, 0, SEEK_END);
+  const long long at = record_start_at_or_after(fd, offset, end > 0 ? (unsigned long long)end : 0ull);
+  close(fd);
+  if (at < 0) {
+    set_error("no FASTQ record boundary found (read error, or not 4-line FASTQ)");
+    return BC_ERR_INVALID;
+  }
+  *start = (uint64_t)at;
+  return BC_OK;
+}
+
 extern "C" int bc_fastq_count(bc_engine* e, const char* fastq_path, uint64_t* total_reads, bc_progress_fn progress,
                               void* user) {
   return fastq_count_impl(e, fastq_path, 0, 1, total_reads, progress, user);
