@@ -143,7 +143,7 @@ bool bc_plan::lower(HostDevPlan& out) const {
     set_error("unsupported scheme: " + unsupported);
     return false;
   }
-  if (length == 0 || length > (uint32_t)kMaxNW * 32u) {
+  if (regex_length == 0 || length > (uint32_t)kMaxNW * 32u) {
     set_error("unsupported scheme: format length must be 1.." + std::to_string(kMaxNW * 32));
     return false;
   }
@@ -157,7 +157,7 @@ bool bc_plan::lower(HostDevPlan& out) const {
   }
   DevPlan& P = out.plan;
   memset(&P, 0, sizeof(P));
-  P.L = length;
+  P.L = regex_length;  // bytes a match spans (shorter than format_string only for a token mixing 'N' and 'n')
   P.RL = (uint32_t)regions_string.size();
   P.max_const = max_constant;
   P.no_repair = lowercase_constants ? 1u : 0u;
@@ -557,13 +557,13 @@ bool bc_plan::lower_long(LongHost& out) const {
     set_error("unsupported scheme: " + unsupported);
     return false;
   }
-  if (length == 0 || length > 65535u) {
+  if (regex_length == 0 || length > 65535u) {
     set_error("unsupported scheme: format length must be 1..65535");
     return false;
   }
   LongPlan& P = out.plan;
   memset(&P, 0, sizeof(P));
-  P.L = length;
+  P.L = regex_length;  // bytes a match spans (shorter than format_string only for a token mixing 'N' and 'n')
   P.RL = (uint32_t)regions_string.size();
   P.max_const = max_constant;
   P.no_repair = lowercase_constants ? 1u : 0u;
@@ -799,7 +799,11 @@ bc_plan* bc_plan_create(const char* text, size_t len) {
       const uint32_t n = (uint32_t)std::count(tok.begin(), tok.end(), 'N');
       p->regex_string += "[AGCT]{" + std::to_string(n) + "}";
       p->format_string += tok;
-      if (n != tok.size()) p->unsupported = "lower-case 'n' in the sequence format";
+      // A token that mixes 'N' and 'n' ("NnN"): the regex asks for as many valid bases as there are UPPER-case N's
+      // while format_string -- what a repair compares windows with and rebuilds the read from -- keeps the whole token
+      // (info.rs:287-295): the format is longer than what the regex matches.  Anchoring follows the regex; whether a
+      // repair can ever succeed is settled once the scheme is complete (below).
+      if (n != tok.size()) p->mixed_n_token = true;
       for (uint32_t d = 0; d < n; ++d) p->pos.push_back({kPosFmtN, 0, -1});
       off += n;
     } else {
@@ -823,6 +827,33 @@ bc_plan* bc_plan_create(const char* text, size_t len) {
     }
   }
   p->length = (uint32_t)p->format_string.size();  // info.rs:307
+  p->regex_length = (uint32_t)p->pos.size();
+  if (p->mixed_n_token) {
+    // fix_constant_region replaces the read by the best window with every non-'N' format character written over it
+    // (parse.rs:270-283) -- the lower-case n's among them -- and the regex is then searched in THAT string
+    // (parse.rs:92-95), at any offset o <= length - regex_length.  A repair can never succeed when at every such
+    // offset some regex position meets a character the format has put there and does not accept it; then the scheme
+    // behaves like one with lower-case constants: anchoring only.  Otherwise a repaired read could match depending on
+    // its bases at a shifted offset: not reproduced, the scheme is refused.
+    const std::string& F = p->format_string;
+    bool never = true;
+    for (uint32_t o = 0; o + p->regex_length <= p->length && never; ++o) {
+      bool rejected = false;
+      for (uint32_t q = 0; q < p->regex_length && !rejected; ++q) {
+        const char c = F[o + q];
+        if (c == 'N') continue;  // the read's own base: unknown here
+        const auto& rp = p->pos[q];
+        if (rp.kind == kPosConst) rejected = c != rp.letter;
+        else if (rp.kind == kPosFmtN) rejected = !(c == 'A' || c == 'C' || c == 'G' || c == 'T');
+        // (a capture group's '.' takes anything)
+      }
+      never = rejected;
+    }
+    if (never)
+      p->lowercase_constants = true;  // (what that flag stands for: no repair can succeed)
+    else
+      p->unsupported = "a token mixing 'N' and 'n' whose repaired reads could still match the format at a shifted offset";
+  }
   p->counted.resize(p->barcode_num);
   p->recompute_budgets();
   return p;

@@ -91,6 +91,8 @@ struct bc_plan {
   std::string unsupported;              // non-empty: why the engine cannot run this scheme
   bool lowercase_constants = false;     // some constant is lower-case in the scheme: no repair can succeed (bc_plan.cpp)
   bool literal_n_constant = false;      // ... and some of them are n's: the regex wants literal 'N' bases
+  bool mixed_n_token = false;           // a token mixes 'N' and 'n': the regex is shorter than format_string (bc_plan.cpp)
+  uint32_t regex_length = 0;            // bytes one regex match spans (= length unless mixed_n_token)
 
   // BarcodeConversions (info.rs:338-343)
   bc::KnownSet samples;

@@ -212,3 +212,31 @@ def test_lower_case_constants_anchor_but_never_repair(variant):
     outc, idx, entries, discard = emu_lib.emulate(plan, seq.reshape(-1), qual.reshape(-1), lens, stride, stride)
     o = parity.check_per_read(c, plan, outc, idx, discard)
     assert o.counters["constant_region"] > upper.counters["constant_region"] and o.counters["matched"] > 0
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_token_mixing_upper_and_lower_case_n(variant):
+    """info.rs:287-295: of a token like "NnN" the regex takes two valid bases ([AGCT]{2}: only the upper-case N's are
+    counted) while format_string keeps all three characters -- the format is one longer than what the regex matches.
+    Anchored reads count by the regex's geometry; a read that needs its constant region repaired is rebuilt from
+    format_string, 'n' and all, and can no longer match (the plan proves that for the scheme, else it refuses it)."""
+    import ngs_barcode_count_amd as pkg
+    c = cases.build_case("del_mismatch_quality", seed=73, n=10)
+    rng = np.random.default_rng(73)
+    # reads generated for the scheme as the REGEX sees it: two free bases where the token stands
+    c["reads"] = readgen.gen_reads(rng, "[8]AGCTACNNGAATCG{8}TGGA{8}TGGA{8}ACTAGAT", 1500, 100, list(c["samples"]), c["counted"],
+                                   p_sub=0.01, p_n=0.004)
+    c["scheme"] = "[8]AGCTACNnNGAATCG{8}TGGA{8}TGGA{8}ACTAGAT"
+    plan = emu_lib.make_plan(c, variant)
+    assert plan.format_string == "NNNNNNNNAGCTACNnNGAATCGNNNNNNNNTGGANNNNNNNNTGGANNNNNNNNACTAGAT"
+    assert plan.regex_string.count("[AGCT]{2}") == 1 and plan.length == len(plan.format_string) == 62
+    seq, qual, lens = readgen.to_arrays(c["reads"])
+    stride = seq.shape[1]
+    outc, idx, entries, discard = emu_lib.emulate(plan, seq.reshape(-1), qual.reshape(-1), lens, stride, stride)
+    o = parity.check_per_read(c, plan, outc, idx, discard)
+    assert o.counters["matched"] > 500 and o.counters["constant_region"] > 100
+    # a scheme whose repaired reads could still match at a shifted offset is refused, not guessed at
+    # ("nN{8}": the repaired read is "n" + nine of the read's own bases, and [AGCT].{8} matches those at offset 1)
+    with pytest.raises(pkg.BarcodeCountError) as err:
+        pkg.Plan("nN{8}", lib=emu_lib.lib(variant)).mode
+    assert "shifted offset" in str(err.value)
