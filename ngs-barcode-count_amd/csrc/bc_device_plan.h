@@ -150,6 +150,10 @@ struct DevPlan {
   uint32_t sparse;      // some group has no known set: its capture's base-5 code is part of the key and
                         // the (then astronomically large) key space is held in a hash map, not a table
   uint64_t rspace;      // 5^rnd_len: key = dense_idx * rspace + code
+  uint64_t dirty_off;   // two-level counting (large dense tables) with an engine-owned table: u32 words from the start
+                        // of the bit map to a byte map with one flag per 64 table entries, set by whoever adds to the
+                        // table -- after a short job the table is almost all zeros (first occurrences live in the
+                        // bit map), and bc_engine_reset zeroes only the flagged 256-byte blocks.  0: no such map
   uint32_t lhash_vec;   // uint4s of the LDS exact-match area (0: none); image of it at lhash_a
   uint64_t lhash_a;
   uint32_t ablate;      // perf-debug only, honoured by -DBC_EXPERIMENT builds alone (`make experiment-lib`): bit mask of

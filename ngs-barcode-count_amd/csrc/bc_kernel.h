@@ -405,6 +405,14 @@ __device__ __forceinline__ uint64_t map_slot(unsigned long long* __restrict__ sl
   }
 }
 
+// a table add that also flags the entry's 256-byte block for the next reset (DevPlan::dirty_off; a plain byte store
+// of 1: idempotent, so no atomic is needed)
+__device__ __forceinline__ void table_add_marked(const DevPlan& pl, uint32_t* __restrict__ table, uint32_t* __restrict__ bits,
+                                                 uint64_t idx) {
+  table_add(&table[idx]);
+  if (bits && pl.dirty_off) reinterpret_cast<uint8_t*>(bits + pl.dirty_off)[idx >> 6] = (uint8_t)1;
+}
+
 // cache policy of the streaming tile fetch: 2 = nt (non-temporal).  Every byte of a batch is read exactly once, so
 // it should not push the correction tables out of L2 or claim Infinity Cache lines; measured 2.3 % on config 3.
 #ifndef BC_DMA_CPOL
@@ -928,7 +936,7 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
     if (bits) {
       const uint32_t n_rep = (uint32_t)__popcll(__ballot(repeat));
       if (n_rep) {
-        if (repeat) table_add(&table[repeat_idx]);
+        if (repeat) table_add_marked(pl, table, bits, repeat_idx);
         ops.pending_add += 1u;
         if (2u * n_rep > (uint32_t)__popcll(__ballot(first_on != 0u))) direct_tiles = 16u;  // mostly repeats
       }
@@ -969,7 +977,7 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
             first_idx = r.dense_idx;
             first_on = 1u;
           } else {
-            table_add(&table[r.dense_idx]);
+            table_add_marked(pl, table, bits, r.dense_idx);
           }
         }
         ops.pending_add += pl.sparse ? 0u : 1u;  // map_slot's compare-and-swap is waited for; the add is not
@@ -977,7 +985,7 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
     }
     ops.mark(9);
   }
-  if (bits && first_on != 0u && ((first_old >> ((uint32_t)first_idx & 31u)) & 1u) != 0u) table_add(&table[first_idx]);
+  if (bits && first_on != 0u && ((first_old >> ((uint32_t)first_idx & 31u)) & 1u) != 0u) table_add_marked(pl, table, bits, first_idx);
 #ifdef BC_PROFILE
   if (lane == 0)
     for (int k = 0; k < 12; ++k) atomicAdd(&bc_g_profile[k], ops.acc[k]);
@@ -996,7 +1004,10 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
   if (hot) {  // the cached counts, one table add per used slot
     for (uint32_t i = tid; i < kHotSlots; i += kTPB) {
       const uint32_t c = hot_cnt[i];
-      if (c) atomicAdd(&table[hot_tag[i]], c);
+      if (c) {
+        atomicAdd(&table[hot_tag[i]], c);
+        if (bits && pl.dirty_off) reinterpret_cast<uint8_t*>(bits + pl.dirty_off)[hot_tag[i] >> 6] = (uint8_t)1;
+      }
     }
   }
 }

@@ -194,3 +194,40 @@ def test_engine_owned_table_pointer_taken_before_the_first_submit(monkeypatch):
     assert _table_dict(view) == exp
     assert eng.result_rows() == workloads_rows(w, n)
     eng.close()
+
+
+@pytest.mark.parametrize("n_sets,n", [((4, 6, 6, 6), 40_000), ((4, 60, 60, 60), 60_000), ((4, 200, 200, 200), 50_000)])
+def test_reset_by_dirty_blocks_leaves_nothing_behind(monkeypatch, n_sets, n):
+    """bc_engine_reset of an engine-owned table with two-level counting zeroes only the 256-byte blocks somebody added
+    to (repeat adds, the hot-counter cache's flush, the straight-to-the-table tiles of a wave that meets mostly repeats):
+    job after job into one engine, every job's rows equal the oracle's for THAT job alone -- tables from tiny (every add
+    a repeat) to sparse (hardly any), and once more after the pointer was handed out (then the whole table is zeroed)"""
+    import ngs_barcode_count_amd as pkg
+    monkeypatch.setenv("BC_BITMAP_MIN_ENTRIES", "1")
+    w = workloads.make("config3", n_sets=n_sets)
+    eng = pkg.Engine(w.plan, device=0)
+    first = 0
+    for job in range(4):
+        m = n if job != 2 else n // 3
+        _submit(w, eng, first, m, chunk=(m // 3) & ~3)
+        exp_counters, exp = _oracle_dense(w, first, m)
+        got = eng.counters()
+        assert {k: got[k] for k in exp_counters} == exp_counters, job
+        assert eng.nonzero_entries() == len(exp), job
+        if job == 3:
+            view = _as_tensor(eng.table_ptr, w.plan.table_entries)  # exposes the table: folded, plain counts
+            assert _table_dict(view) == exp
+        else:
+            s, b, c = eng.rows()
+            sizes = [len(x) for x in w.counted]
+            got_rows = {}
+            for i in range(len(c)):
+                di = int(s[i])
+                for k in range(3):
+                    di = di * sizes[k] + int(b[i, k])
+                got_rows[di] = int(c[i])
+            assert got_rows == exp, job
+        first += m
+        eng.reset()
+        assert eng.nonzero_entries() == 0, job
+    eng.close()
