@@ -267,21 +267,21 @@ class Run:
         dist = torch.distributed
         n, R, steps, world, rank, dev = self.n, self.R, self.steps, self.world, self.rank, self.dev
         step_no = [0]
-        carried = dict.fromkeys(pkg.COUNTER_NAMES, 0)  # outcome counters of the passes before a reset
+        carried = dict.fromkeys(pkg.COUNTER_NAMES, 0)  # (outcome counters survive reset_results: nothing to carry)
         resets = []
 
         def step():
+            # One step = one job of the BASELINE size: `n` reads nobody has counted before, into an empty Results.  (Rounds
+            # 1-2 let the steps accumulate in one table: the kernel then slows down step by step as the 4 x 10^9 tuples
+            # fill up -- every repeat is a second atomic --, which measured a 2 G-read job the config does not name.)
+            # The emptying between jobs is part of the timed region: bc_engine_reset_results zeroes the blocks the last
+            # job touched (two-level counting leaves the table almost all zeros) and the bit map.
             k = step_no[0] % self.n_batches
             if self.random_mode:
-                eng.clear_keys()  # a step is one whole job: otherwise every later step would see only duplicates
-            elif k == 0 and step_no[0] > 0:
-                # every resident batch has been counted once: a job never counts a read twice, so the next pass over
-                # them is a new job -- counters read, table (and bit map) zeroed; inside the timed region, reported
-                t_r = time.perf_counter()
-                for key, v in eng.counters().items():
-                    carried[key] += v
-                eng.reset()
-                resets.append((time.perf_counter() - t_r) * 1e3)
+                eng.clear_keys()
+            elif step_no[0] > 0:
+                eng.reset_results()
+                resets.append(0.0)
             bs, bq = self.batches[k]
             step_no[0] += 1
             eng.submit_device(bs.data_ptr(), bq.data_ptr() if bq is not None else None, n, R, R)
@@ -373,7 +373,9 @@ class Run:
         except (OSError, ValueError, KeyError):
             pass
         res = {"config": self.name, "workload": WORKLOAD_TEXT[self.name], "reads_per_step_per_gpu": n, "read_len": R,
-               "distinct_batches": self.n_batches, "resets_in_region": len(resets), "reset_in_region_ms": sum(resets),
+               "distinct_batches": self.n_batches, "resets_in_region": len(resets),
+               # (not timed one by one -- that would need a sync per step; reset_ms is one of them with its sync)
+               "reset_in_region_ms": len(resets) * reset_ms,
                "value": total_reads / elapsed, "ms_per_step": elapsed * 1e3 / steps, "reduce_ms": reduce_ms,
                "reset_ms": reset_ms, "outcomes": {k: counters[k] for k in pkg.COUNTER_NAMES}, "roofline": roof}
         if not self.random_mode and world == 1 and w.plan.table_entries:

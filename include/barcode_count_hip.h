@@ -136,6 +136,10 @@ int bc_engine_submit_host(bc_engine *e, const void *seq, const void *qual, const
 int bc_engine_sync(bc_engine *e);
 /* zero the table and the counters (a fresh Results::new, info.rs:678) */
 int bc_engine_reset(bc_engine *e);
+/* the same without the outcome counters: a fresh Results (table, bit map, key set / map) for the next sample of a run
+ * whose SequenceErrors go on counting.  Large engine-owned tables are reset by the blocks that were touched (they are
+ * almost all zeros after a job: first occurrences live in the bit map), not by a 16 GB memset. */
+int bc_engine_reset_results(bc_engine *e);
 
 /* SequenceErrors values (u64; the reference wraps at 2^32, info.rs:17-22) */
 int bc_engine_counters(bc_engine *e, uint64_t out[BC_NCOUNTERS]);

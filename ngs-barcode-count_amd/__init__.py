@@ -177,6 +177,10 @@ class Engine:
     def reset(self):
         _check(self._lib, self._lib.bc_engine_reset(self._e))
 
+    def reset_results(self):
+        """a fresh Results (table / bit map / keys); the outcome counters go on"""
+        _check(self._lib, self._lib.bc_engine_reset_results(self._e))
+
     def counters(self):
         out = (C.c_uint64 * 8)()
         _check(self._lib, self._lib.bc_engine_counters(self._e, out))

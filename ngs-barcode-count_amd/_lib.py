@@ -71,6 +71,7 @@ ENGINE_API = {
     "bc_engine_submit_host": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u64]),
     "bc_engine_sync": (_int, [_vp]),
     "bc_engine_reset": (_int, [_vp]),
+    "bc_engine_reset_results": (_int, [_vp]),
     "bc_engine_counters": (_int, [_vp, C.POINTER(C.c_uint64)]),
     "bc_engine_table_ptr": (_vp, [_vp]),
     "bc_engine_counters_ptr": (_vp, [_vp]),
