@@ -19,6 +19,8 @@
 
 using namespace bc;
 
+extern "C" void* bc_internal_table_folded(bc_engine* e);  // bc_engine.hip
+
 #define HIPC(expr)                                                                   \
   do {                                                                               \
     hipError_t _e = (expr);                                                          \
@@ -552,7 +554,7 @@ int bc_engine_reduce_all(bc_engine* e, bc_comm* c, int root, uint64_t counters[B
     if (random && !sparse && (rc = bc_engine_materialize_table(e))) return rc;  // the owned keys' per-tuple distinct counts
   }
   if (!sparse) {
-    uint32_t* table = (uint32_t*)bc_engine_table_ptr(e);  // plain u32 counts (two-level counting folded)
+    uint32_t* table = (uint32_t*)bc_internal_table_folded(e);  // plain u32 counts (two-level counting folded)
     if ((rc = status(reduce_tables(t, ops, table, bc_engine_table_entries(e), root)))) return rc;
   }
   if ((rc = status(t.reduce_sum_u64(local, BC_NCOUNTERS, root)))) return rc;
