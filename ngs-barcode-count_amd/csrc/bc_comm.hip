@@ -19,7 +19,12 @@
 
 using namespace bc;
 
-extern "C" void* bc_internal_table_folded(bc_engine* e);  // bc_engine.hip
+extern "C" {  // bc_engine.hip (not part of the documented ABI)
+void* bc_internal_table_unfolded(bc_engine* e, const void** bits);
+int bc_internal_table_now_plain(bc_engine* e);
+int bc_internal_table_pack_u8(const void* d_table_u32, const void* d_bits, uint64_t n, void* d_out_u8, void* d_ovf_idx_u64,
+                              void* d_ovf_val_u32, uint64_t ovf_capacity, uint64_t* n_ovf, int device_id, void* hip_stream);
+}
 
 #define HIPC(expr)                                                                   \
   do {                                                                               \
@@ -128,6 +133,10 @@ uint32_t grid_of(uint64_t n) { return (uint32_t)std::min<uint64_t>((n + 255) / 2
 struct HipOps {
   int device;
   hipStream_t st;
+  // the engine's own table may come with its first-occurrence bit map still apart (two-level counting): packed as
+  // table + bit, no fold pass first
+  const uint32_t* engine_table = nullptr;
+  const void* engine_bits = nullptr;
   void* alloc(size_t bytes) {
     void* p = nullptr;
     const hipError_t rc = hipMalloc(&p, bytes ? bytes : 16);
@@ -159,7 +168,8 @@ struct HipOps {
         return BC_ERR_NOMEM;
       }
       uint64_t need = 0;
-      int rc = bc_table_pack_u8(table, n, out, d_idx, d_val, cap, &need, device, st);  // (waits for the stream)
+      int rc = bc_internal_table_pack_u8(table, table == engine_table ? engine_bits : nullptr, n, out, d_idx, d_val, cap, &need, device,
+                                         st);  // (waits for the stream)
       if (rc == BC_OK && need <= cap && need) {
         ovf_idx.resize(need);
         ovf_val.resize(need);
@@ -554,8 +564,11 @@ int bc_engine_reduce_all(bc_engine* e, bc_comm* c, int root, uint64_t counters[B
     if (random && !sparse && (rc = bc_engine_materialize_table(e))) return rc;  // the owned keys' per-tuple distinct counts
   }
   if (!sparse) {
-    uint32_t* table = (uint32_t*)bc_internal_table_folded(e);  // plain u32 counts (two-level counting folded)
+    // (two-level counting: the bit map travels inside the packed bytes -- table + bit --, not through a fold pass)
+    uint32_t* table = (uint32_t*)bc_internal_table_unfolded(e, &ops.engine_bits);
+    ops.engine_table = table;
     if ((rc = status(reduce_tables(t, ops, table, bc_engine_table_entries(e), root)))) return rc;
+    if ((rc = bc_internal_table_now_plain(e))) return rc;  // root: the table is the job's sum; others: unspecified anyway
   }
   if ((rc = status(t.reduce_sum_u64(local, BC_NCOUNTERS, root)))) return rc;
   if (counters) {

@@ -30,6 +30,8 @@ def _oracle(case, n):
 
 
 @pytest.mark.parametrize("case,world,n,root", [("dense", 2, 60_001, 0), ("dense", 3, 40_000, 2), ("dense_hot", 2, 50_000, 1),
+                                               # (two-level counting on: the bit map travels inside the packed bytes)
+                                               ("dense+bits", 2, 60_001, 1), ("dense_hot+bits", 3, 50_000, 0),
                                                ("random", 2, 60_000, 0), ("random", 3, 45_000, 1),
                                                ("sparse", 2, 30_000, 0), ("sparse_random", 3, 30_000, 2)])
 def test_ranks_on_one_gpu_equal_the_oracle(tmp_path, case, world, n, root):
@@ -37,6 +39,9 @@ def test_ranks_on_one_gpu_equal_the_oracle(tmp_path, case, world, n, root):
     cdir.mkdir()
     out = tmp_path / "job.json"
     env = dict(os.environ, BC_COMM_TIMEOUT_S="120")
+    if case.endswith("+bits"):
+        case = case[:-5]
+        env["BC_BITMAP_MIN_ENTRIES"] = "1"
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_rank.py"), case, str(r), str(world), str(cdir),
                                str(n), str(root), str(out)], env=env, stderr=subprocess.PIPE) for r in range(world)]
     for r, p in enumerate(procs):
