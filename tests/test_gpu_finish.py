@@ -231,3 +231,26 @@ def test_reset_by_dirty_blocks_leaves_nothing_behind(monkeypatch, n_sets, n):
         eng.reset()
         assert eng.nonzero_entries() == 0, job
     eng.close()
+
+
+def test_reset_results_keeps_the_outcome_counters():
+    """bc_engine_reset_results: a fresh Results for the next sample, SequenceErrors go on (what bench.py does between
+    its steps); bc_engine_reset clears both"""
+    import ngs_barcode_count_amd as pkg
+    w = workloads.make("config3", n_sets=(4, 40, 40, 40))
+    eng = pkg.Engine(w.plan, device=0)
+    n = 30_000
+    _submit(w, eng, 0, n)
+    c1, _ = _oracle_dense(w, 0, n)
+    eng.reset_results()
+    assert eng.nonzero_entries() == 0
+    got = eng.counters()
+    assert {k: got[k] for k in c1} == c1 and got["total_reads"] == n
+    _submit(w, eng, n, n)
+    c2, exp2 = _oracle_dense(w, n, n)
+    got = eng.counters()
+    assert {k: got[k] for k in c1} == {k: c1[k] + c2[k] for k in c1}
+    assert eng.nonzero_entries() == len(exp2)  # the second sample's rows only
+    eng.reset()
+    assert sum(eng.counters().values()) == 0 and eng.result_rows() == []
+    eng.close()
