@@ -69,6 +69,57 @@ __global__ void comm_sum_u8_kernel(const uint8_t* __restrict__ rows, uint32_t n_
   }
 }
 
+// out[i] = how many of the n_rows bit maps (`words` u32 each, back to back) have bit i, i < len: one word column per thread
+__global__ void comm_sum_bits_kernel(const uint32_t* __restrict__ rows, uint32_t n_rows, uint64_t words, uint64_t len,
+                                     uint32_t* __restrict__ out) {
+  uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  for (; j < words; j += step) {
+    uint32_t c[32];
+#pragma unroll
+    for (int b = 0; b < 32; ++b) c[b] = 0;
+    for (uint32_t r = 0; r < n_rows; ++r) {
+      const uint32_t w = rows[(uint64_t)r * words + j];
+#pragma unroll
+      for (int b = 0; b < 32; ++b) c[b] += (w >> b) & 1u;
+    }
+    const uint64_t first = j * 32;
+    if (first + 32 <= len) {
+      uint4* o = reinterpret_cast<uint4*>(out + first);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o[q] = make_uint4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
+    } else {
+#pragma unroll
+      for (int b = 0; b < 32; ++b)
+        if (first + (uint64_t)b < len) out[first + b] = c[b];
+    }
+  }
+}
+
+// the non-zero entries of a table as (index, value) pairs, in no particular order (one cursor add per wavefront)
+__global__ void comm_table_nonzero_kernel(const uint32_t* __restrict__ table, uint64_t n, unsigned long long* cursor, uint64_t capacity,
+                                          unsigned long long* __restrict__ out_idx, uint32_t* __restrict__ out_val) {
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < n; base += step) {
+    const uint64_t i = base + threadIdx.x;
+    const uint32_t v = i < n ? table[i] : 0u;
+    const unsigned long long m = __ballot(v != 0u);
+    if (m == 0ull) continue;
+    unsigned long long first = 0;
+    const unsigned leader = (unsigned)(__ffsll((long long)m) - 1);
+    if (__lane_id() == leader) first = atomicAdd(cursor, (unsigned long long)__popcll(m));
+    first = ((unsigned long long)(unsigned)__shfl((int)(first >> 32), (int)leader) << 32) |
+            (unsigned long long)(unsigned)__shfl((int)first, (int)leader);
+    if (v) {
+      const unsigned long long p = first + (unsigned long long)__popcll(m & ((1ull << __lane_id()) - 1ull));
+      if (p < capacity) {
+        out_idx[p] = i;
+        out_val[p] = v;
+      }
+    }
+  }
+}
+
 __global__ void comm_widen_u8_kernel(const uint8_t* __restrict__ src, uint64_t n, uint32_t* __restrict__ dst) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
@@ -191,6 +242,50 @@ struct HipOps {
     hipLaunchKernelGGL(comm_sum_u8_kernel, dim3(grid_of(len / 4 + 1)), dim3(256), 0, st, rows, n_rows, len, out);
     HIPC(hipGetLastError());
     return 0;
+  }
+  int sum_bits(const uint32_t* rows, uint32_t n_rows, uint64_t words, uint64_t len, uint32_t* out) {
+    if (len == 0) return 0;
+    hipLaunchKernelGGL(comm_sum_bits_kernel, dim3(grid_of(words)), dim3(256), 0, st, rows, n_rows, words, len, out);
+    HIPC(hipGetLastError());
+    return 0;
+  }
+  int table_nonzero(const uint32_t* table, uint64_t n, uint64_t cap, std::vector<uint64_t>& idx, std::vector<uint32_t>& val, bool& fits) {
+    idx.clear();
+    val.clear();
+    fits = true;
+    if (n == 0) return 0;
+    unsigned long long *d_n = nullptr, *d_idx = nullptr;
+    uint32_t* d_val = nullptr;
+    int rc = 0;
+    if (hipMalloc((void**)&d_n, 8) != hipSuccess || hipMalloc((void**)&d_idx, cap * 8) != hipSuccess ||
+        hipMalloc((void**)&d_val, cap * 4) != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("exchange: out of device memory for the table's non-zero entries");
+      rc = BC_ERR_NOMEM;
+    }
+    unsigned long long need = 0;
+    if (!rc) {
+      if (hipMemsetAsync(d_n, 0, 8, st) != hipSuccess) rc = BC_ERR_HIP;
+      hipLaunchKernelGGL(comm_table_nonzero_kernel, dim3(grid_of(n)), dim3(256), 0, st, table, n, d_n, cap, d_idx, d_val);
+      if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&need, d_n, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+          hipStreamSynchronize(st) != hipSuccess)
+        rc = BC_ERR_HIP;
+    }
+    if (!rc) {
+      fits = need <= cap;
+      if (fits && need) {
+        idx.resize(need);
+        val.resize(need);
+        if (hipMemcpy(idx.data(), d_idx, need * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(val.data(), d_val, need * 4, hipMemcpyDeviceToHost) != hipSuccess)
+          rc = BC_ERR_HIP;
+      }
+    }
+    if (d_n) (void)hipFree(d_n);
+    if (d_idx) (void)hipFree(d_idx);
+    if (d_val) (void)hipFree(d_val);
+    if (rc == BC_ERR_HIP) set_error("exchange: collecting the table's non-zero entries failed");
+    return rc;
   }
   int widen_u8(const uint8_t* src, uint64_t n, uint32_t* dst) {
     if (n == 0) return 0;
@@ -567,7 +662,7 @@ int bc_engine_reduce_all(bc_engine* e, bc_comm* c, int root, uint64_t counters[B
     // (two-level counting: the bit map travels inside the packed bytes -- table + bit --, not through a fold pass)
     uint32_t* table = (uint32_t*)bc_internal_table_unfolded(e, &ops.engine_bits);
     ops.engine_table = table;
-    if ((rc = status(reduce_tables(t, ops, table, bc_engine_table_entries(e), root)))) return rc;
+    if ((rc = status(reduce_tables(t, ops, table, (const uint32_t*)ops.engine_bits, bc_engine_table_entries(e), root)))) return rc;
     if ((rc = bc_internal_table_now_plain(e))) return rc;  // root: the table is the job's sum; others: unspecified anyway
   }
   if ((rc = status(t.reduce_sum_u64(local, BC_NCOUNTERS, root)))) return rc;

@@ -22,6 +22,11 @@
 //                                                    keys (`words` u64 each; the owner comes from the first word, which
 //                                                    for a wide key is a fingerprint of the rest) grouped by owner rank
 //                                                    (key_owner(), or fixed_owner >= 0)
+//   int table_nonzero(const uint32_t* table, uint64_t n, uint64_t cap, std::vector<uint64_t>& idx,
+//                     std::vector<uint32_t>& val, bool& fits)   the non-zero entries as host lists; fits = false (lists
+//                                                    unspecified) when there are more than cap
+//   int sum_bits(const uint32_t* rows, uint32_t n_rows, uint64_t words, uint64_t len, uint32_t* out)
+//                                                    out[i] = number of the n_rows bit maps (words u32 each) with bit i
 //   int sync()                                       everything above has finished
 #pragma once
 #include <algorithm>
@@ -38,8 +43,9 @@ inline int key_owner(uint64_t key, int world) {
   return (int)((x >> 7) % (uint64_t)world);
 }
 
-// slice r of a table of n entries cut for `world` ranks: [slice_begin(r), slice_begin(r + 1)), multiples of 4 entries
-inline uint64_t slice_len(uint64_t n, int world) { return ((n + (uint64_t)world - 1) / (uint64_t)world + 3) & ~3ull; }
+// slice r of a table of n entries cut for `world` ranks: [slice_begin(r), slice_begin(r + 1)), multiples of 64 entries
+// (whole words of a bit map, whole uint4s of bytes)
+inline uint64_t slice_len(uint64_t n, int world) { return ((n + (uint64_t)world - 1) / (uint64_t)world + 63) & ~63ull; }
 inline uint64_t slice_begin(uint64_t n, int world, int r) { return std::min(n, slice_len(n, world) * (uint64_t)r); }
 
 template <class Ops>
@@ -107,48 +113,87 @@ int exchange_pairs(Transport& t, std::vector<uint64_t>& idx, std::vector<uint32_
 //      bytes);
 //   2. each rank adds up the slices it received (one pass at HBM speed) and the side-list entries addressed to it;
 //   3. the summed slices go to the root point to point, again as bytes + side list, one link each.
+// `bits` (may be null): two-level counting -- the count of entry i is table[i] + bit i of this map.  After a short job
+// nearly every count IS its bit (the table holds the repeats only), and step 1 then sends the bit map's slices as they
+// stand -- an eighth of the bytes again, no pack pass -- with the table's few non-zero entries in the side list; used
+// when every rank's table is that sparse (at most one entry in 64), else table + bit go into the bytes.
 template <class Ops>
-int reduce_tables(Transport& t, Ops& ops, uint32_t* table, uint64_t n, int root) {
+int reduce_tables(Transport& t, Ops& ops, uint32_t* table, const uint32_t* bits, uint64_t n, int root, bool* took_bits = nullptr) {
   const int W = t.world, me = t.rank;
+  if (took_bits) *took_bits = false;
   if (W <= 1 || n == 0) return 0;
   Scoped<Ops> mem(ops);
   const uint64_t my_begin = slice_begin(n, W, me), my_len = slice_begin(n, W, me + 1) - my_begin;
   const uint64_t cut = slice_len(n, W);
-  // 1. packed slices to their owners
-  uint8_t* packed = mem.template get<uint8_t>((size_t)n + 16);
-  uint8_t* recv = mem.template get<uint8_t>((size_t)(my_len * (uint64_t)W) + 16);
-  uint32_t* part = mem.template get<uint32_t>((size_t)my_len + 4);
-  if (!packed || !recv || !part) return -4;
   std::vector<uint64_t> o_idx, i_idx;
   std::vector<uint32_t> o_val, i_val;
-  int rc = ops.pack_u8(table, n, packed, o_idx, o_val);
-  if (rc) return rc;
   std::vector<uint64_t> sb((size_t)W), rb((size_t)W);
-  for (int r = 0; r < W; ++r) {
-    sb[(size_t)r] = slice_begin(n, W, r + 1) - slice_begin(n, W, r);
-    rb[(size_t)r] = my_len;
+  int rc;
+  // which form step 1 takes: every rank must agree
+  bool as_bits = false;
+  {
+    bool fits = false;
+    if (bits && (rc = ops.table_nonzero(table, n, std::max<uint64_t>(1024, n / 64), o_idx, o_val, fits))) return rc;
+    std::vector<uint64_t> mine((size_t)W, (bits && fits) ? 1u : 0u), theirs((size_t)W, 0);
+    if ((rc = t.exchange_counts(mine.data(), theirs.data()))) return rc;
+    as_bits = true;
+    for (uint64_t v : theirs) as_bits = as_bits && v != 0;
+    if (took_bits) *took_bits = as_bits;
   }
-  if ((rc = ops.sync())) return rc;
-  if ((rc = t.all_to_all_v(packed, sb.data(), recv, rb.data()))) return rc;
-  if ((rc = exchange_pairs(t, o_idx, o_val, [&](uint64_t i) { return (int)(i / cut); }, i_idx, i_val))) return rc;
-  // 2. one pass over what arrived
-  if ((rc = ops.sum_u8(recv, (uint32_t)W, my_len, part))) return rc;
+  uint32_t* part = mem.template get<uint32_t>((size_t)my_len + 4);
+  if (!part) return -4;
+  uint8_t* packed = nullptr;  // n bytes: step 1's send buffer in the byte form, the root's view in step 3
+  uint8_t* recv = nullptr;
+  if (as_bits) {
+    // 1b. bit-map slices to their owners (slice boundaries are multiples of 64 entries: whole words)
+    const uint64_t my_words = (my_len + 31) / 32;
+    recv = mem.template get<uint8_t>((size_t)(std::max(my_words * 4 * (uint64_t)W, my_len)) + 16);
+    if (!recv) return -4;
+    for (int r = 0; r < W; ++r) {
+      sb[(size_t)r] = ((slice_begin(n, W, r + 1) - slice_begin(n, W, r) + 31) / 32) * 4;
+      rb[(size_t)r] = my_words * 4;
+    }
+    if ((rc = ops.sync())) return rc;
+    if ((rc = t.all_to_all_v(bits, sb.data(), recv, rb.data()))) return rc;
+    if ((rc = exchange_pairs(t, o_idx, o_val, [&](uint64_t i) { return (int)(i / cut); }, i_idx, i_val))) return rc;
+    // 2b. per entry, how many ranks have its bit
+    if ((rc = ops.sum_bits(reinterpret_cast<const uint32_t*>(recv), (uint32_t)W, my_words, my_len, part))) return rc;
+  } else {
+    // 1. packed slices to their owners
+    packed = mem.template get<uint8_t>((size_t)n + 16);
+    recv = mem.template get<uint8_t>((size_t)(my_len * (uint64_t)W) + 16);
+    if (!packed || !recv) return -4;
+    if ((rc = ops.pack_u8(table, n, packed, o_idx, o_val))) return rc;  // (table + bit where a bit map is given to ops)
+    for (int r = 0; r < W; ++r) {
+      sb[(size_t)r] = slice_begin(n, W, r + 1) - slice_begin(n, W, r);
+      rb[(size_t)r] = my_len;
+    }
+    if ((rc = ops.sync())) return rc;
+    if ((rc = t.all_to_all_v(packed, sb.data(), recv, rb.data()))) return rc;
+    if ((rc = exchange_pairs(t, o_idx, o_val, [&](uint64_t i) { return (int)(i / cut); }, i_idx, i_val))) return rc;
+    // 2. one pass over what arrived
+    if ((rc = ops.sum_u8(recv, (uint32_t)W, my_len, part))) return rc;
+  }
   if (!i_idx.empty()) {
     for (uint64_t& i : i_idx) i -= my_begin;
     if ((rc = ops.scatter_add(part, i_idx.data(), i_val.data(), i_idx.size()))) return rc;
   }
-  // 3. summed slices to the root, packed again (the buffers of step 1 are free: reuse `packed` for the root's view)
+  // 3. summed slices to the root, as bytes + side list
   o_idx.clear();
   o_val.clear();
-  uint8_t* mine8 = recv;  // (my_len bytes of it)
+  uint8_t* mine8 = recv;  // (my_len bytes of it: what arrived has been summed)
   if ((rc = ops.pack_u8(part, my_len, mine8, o_idx, o_val))) return rc;
   for (uint64_t& i : o_idx) i += my_begin;
+  if (me == root && !packed) {
+    packed = mem.template get<uint8_t>((size_t)n + 16);
+    if (!packed) return -4;
+  }
   for (int r = 0; r < W; ++r) {
     sb[(size_t)r] = r == root ? my_len : 0;
     rb[(size_t)r] = me == root ? slice_begin(n, W, r + 1) - slice_begin(n, W, r) : 0;
   }
   if ((rc = ops.sync())) return rc;
-  if ((rc = t.all_to_all_v(mine8, sb.data(), packed, rb.data()))) return rc;
+  if ((rc = t.all_to_all_v(mine8, sb.data(), packed ? packed : mine8, rb.data()))) return rc;
   if ((rc = exchange_pairs(t, o_idx, o_val, [&](uint64_t) { return root; }, i_idx, i_val))) return rc;
   if (me == root) {
     if ((rc = ops.widen_u8(packed, n, table))) return rc;

@@ -35,12 +35,13 @@ struct HostOps {
     oi.clear();
     ov.clear();
     for (uint64_t i = 0; i < n; ++i) {
-      if (table[i] <= 255u) {
-        out[i] = (uint8_t)table[i];
+      const uint32_t c = table[i] + ((table == engine_table && engine_bits) ? (engine_bits[i >> 5] >> (i & 31)) & 1u : 0u);
+      if (c <= 255u) {
+        out[i] = (uint8_t)c;
       } else {
         out[i] = 0;
         oi.push_back(i);
-        ov.push_back(table[i]);
+        ov.push_back(c);
       }
     }
     return 0;
@@ -51,6 +52,28 @@ struct HostOps {
       for (uint32_t r = 0; r < n_rows; ++r) a += rows[(uint64_t)r * len + i];
       out[i] = a;
     }
+    return 0;
+  }
+  // (the test's stand-in for an engine's bit map beside its table: count = table + bit)
+  const uint32_t* engine_table = nullptr;
+  const uint32_t* engine_bits = nullptr;
+  int sum_bits(const uint32_t* rows, uint32_t n_rows, uint64_t words, uint64_t len, uint32_t* out) {
+    for (uint64_t i = 0; i < len; ++i) {
+      uint32_t a = 0;
+      for (uint32_t r = 0; r < n_rows; ++r) a += (rows[(uint64_t)r * words + (i >> 5)] >> (i & 31)) & 1u;
+      out[i] = a;
+    }
+    return 0;
+  }
+  int table_nonzero(const uint32_t* table, uint64_t n, uint64_t cap, std::vector<uint64_t>& idx, std::vector<uint32_t>& val, bool& fits) {
+    idx.clear();
+    val.clear();
+    for (uint64_t i = 0; i < n; ++i)
+      if (table[i]) {
+        idx.push_back(i);
+        val.push_back(table[i]);
+      }
+    fits = idx.size() <= cap;
     return 0;
   }
   int widen_u8(const uint8_t* src, uint64_t n, uint32_t* dst) {
@@ -107,9 +130,30 @@ int main(int argc, char** argv) {
   HostOps ops;
   int rc = 0;
   if (kind == "tables") {
-    std::vector<uint32_t> table(n + 4);
-    for (uint64_t i = 0; i < n; ++i) table[i] = table_value(seed, rank, i);
-    rc = bc::reduce_tables(t, ops, table.data(), n, root);
+    // argv[9]: "" plain tables; "bits": the counts split into a first-occurrence bit map and a table that is nearly
+    // empty (the exchange's bit-map form); "bits_dense": split the same way but with tables too full for that form on
+    // the odd ranks, so that every rank has to fall back to bytes together
+    const std::string how = argc > 9 ? argv[9] : "";
+    std::vector<uint32_t> table(n + 4), bits((n + 31) / 32 + 4, 0u);
+    for (uint64_t i = 0; i < n; ++i) {
+      uint32_t c = table_value(seed, rank, i);
+      if (how == "bits") c = (mix(seed ^ (i * 31 + (uint64_t)rank)) % 97 == 0) ? c : (c ? 1u : 0u);  // mostly 0 / 1
+      if (!how.empty() && c) {
+        const bool dense_here = how == "bits_dense" && (rank & 1);
+        if (!dense_here || (mix(i + 5) & 1)) {
+          bits[i >> 5] |= 1u << (i & 31);
+          c -= 1u;
+        }
+      }
+      table[i] = c;
+    }
+    if (!how.empty()) {
+      ops.engine_table = table.data();
+      ops.engine_bits = bits.data();
+    }
+    bool took_bits = false;
+    rc = bc::reduce_tables(t, ops, table.data(), how.empty() ? nullptr : bits.data(), n, root, &took_bits);
+    if (rank == root) printf("form %s\n", took_bits ? "bits" : "bytes");
     uint64_t counters[3] = {(uint64_t)rank + 1, 10, n};
     if (!rc) rc = t.reduce_sum_u64(counters, 3, root);
     if (!rc && rank == root) {

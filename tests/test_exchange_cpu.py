@@ -54,26 +54,44 @@ def _run_ranks(tmp_path, world, args_of):
     exe = _build()
     d = tmp_path / "msgs"
     d.mkdir()
-    procs = [subprocess.Popen([exe, str(d), str(r), str(world)] + args_of(r), stderr=subprocess.PIPE) for r in range(world)]
+    procs = [subprocess.Popen([exe, str(d), str(r), str(world)] + args_of(r), stderr=subprocess.PIPE, stdout=subprocess.PIPE)
+             for r in range(world)]
+    said = ""
     for r, p in enumerate(procs):
-        _, err = p.communicate(timeout=120)
+        out, err = p.communicate(timeout=120)
         assert p.returncode == 0, (r, err.decode()[-500:])
+        said += out.decode()
     assert os.listdir(d) == []  # every message was consumed
+    return said
 
 
-@pytest.mark.parametrize("world,n,root", [(2, 4096, 0), (3, 10_001, 2), (5, 777, 1), (2, 3, 1), (4, 2, 0)])
-def test_tables_are_summed_onto_the_root(tmp_path, world, n, root):
-    """table lengths that do and do not divide by 4 x world, slices that come out empty, counts on both sides of the
-    byte limit, u32 sums that wrap"""
+def _sparse_count(seed, r, n, c):
+    """what exchange_host's "bits" mode makes of a rank's counts: mostly 0 / 1, the full value for one entry in 97"""
+    i = np.arange(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        keep = _mix(np.uint64(seed) ^ (i * np.uint64(31) + np.uint64(r))) % np.uint64(97) == 0
+    return np.where(keep, c, (c != 0).astype(np.uint32)).astype(np.uint32)
+
+
+@pytest.mark.parametrize("world,n,root,how", [(2, 4096, 0, ""), (3, 10_001, 2, ""), (5, 777, 1, ""), (2, 3, 1, ""), (4, 2, 0, ""),
+                                              (2, 100_000, 1, "bits"), (3, 70_001, 0, "bits"), (5, 200_003, 4, "bits"),
+                                              (3, 70_001, 2, "bits_dense"), (2, 130, 0, "bits")])
+def test_tables_are_summed_onto_the_root(tmp_path, world, n, root, how):
+    """table lengths that do and do not divide by 64 x world, slices that come out empty, counts on both sides of the
+    byte limit, u32 sums that wrap; "bits": counts split into a first-occurrence bit map and a nearly empty table, which
+    travel as bit-map slices + a side list; "bits_dense": the same split with tables too full for that on some ranks --
+    all ranks then fall back to bytes (table + bit) together"""
     out = tmp_path / "sum.bin"
-    _run_ranks(tmp_path, world, lambda r: ["tables", str(n), "42", str(root), str(out)])
+    said = _run_ranks(tmp_path, world, lambda r: ["tables", str(n), "42", str(root), str(out), how])
+    assert ("form bits" in said) == (how == "bits"), said  # the form every rank agreed on
     raw = np.fromfile(out, dtype=np.uint8)
     got = raw[: 4 * n].view(np.uint32)
     counters = raw[4 * n:].view(np.uint64)
     exp = np.zeros(n, dtype=np.uint32)
     with np.errstate(over="ignore"):
         for r in range(world):
-            exp = exp + _table(42, r, n)  # u32 arithmetic: wraps like the engine's atomics
+            c = _table(42, r, n)
+            exp = exp + (_sparse_count(42, r, n, c) if how == "bits" else c)  # u32 arithmetic: wraps like the engine's atomics
     assert np.array_equal(got, exp)
     assert counters.tolist() == [world * (world + 1) // 2, 10 * world, n * world]
 
