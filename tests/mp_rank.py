@@ -17,6 +17,8 @@ def make_case(case):
     import workloads
     if case == "dense":
         return workloads.make("config3", n_sets=(4, 60, 60, 60))
+    if case == "dense_big":  # 32 M tuples: with two-level counting on, the tables stay sparse enough for the exchange's bit-map form
+        return workloads.make("config3", n_sets=(4, 200, 200, 200))
     if case == "dense_hot":  # few tuples, many reads: counts far above 255 (the overflow side list of the byte-packed exchange)
         return workloads.make("config3", n_sets=(2, 3, 3, 3))
     if case == "random":

@@ -32,6 +32,8 @@ def _oracle(case, n):
 @pytest.mark.parametrize("case,world,n,root", [("dense", 2, 60_001, 0), ("dense", 3, 40_000, 2), ("dense_hot", 2, 50_000, 1),
                                                # (two-level counting on: the bit map travels inside the packed bytes)
                                                ("dense+bits", 2, 60_001, 1), ("dense_hot+bits", 3, 50_000, 0),
+                                               # (... or, tables sparse enough, as bit-map slices + the tables' non-zero entries)
+                                               ("dense_big+bits", 3, 90_000, 2),
                                                ("random", 2, 60_000, 0), ("random", 3, 45_000, 1),
                                                ("sparse", 2, 30_000, 0), ("sparse_random", 3, 30_000, 2)])
 def test_ranks_on_one_gpu_equal_the_oracle(tmp_path, case, world, n, root):
