@@ -662,7 +662,12 @@ int bc_engine_reduce_all(bc_engine* e, bc_comm* c, int root, uint64_t counters[B
     // (two-level counting: the bit map travels inside the packed bytes -- table + bit --, not through a fold pass)
     uint32_t* table = (uint32_t*)bc_internal_table_unfolded(e, &ops.engine_bits);
     ops.engine_table = table;
-    if ((rc = status(reduce_tables(t, ops, table, (const uint32_t*)ops.engine_bits, bc_engine_table_entries(e), root)))) return rc;
+    bool took_bits = false;
+    if ((rc = status(reduce_tables(t, ops, table, (const uint32_t*)ops.engine_bits, bc_engine_table_entries(e), root, &took_bits))))
+      return rc;
+    if (t.rank == root && getenv("BC_COMM_VERBOSE"))
+      fprintf(stderr, "[barcode-count] table exchange over %d ranks: %s\n", t.world,
+              took_bits ? "bit-map slices + the tables' non-zero entries" : "byte-packed slices");
     if ((rc = bc_internal_table_now_plain(e))) return rc;  // root: the table is the job's sum; others: unspecified anyway
   }
   if ((rc = status(t.reduce_sum_u64(local, BC_NCOUNTERS, root)))) return rc;

@@ -40,15 +40,22 @@ def test_ranks_on_one_gpu_equal_the_oracle(tmp_path, case, world, n, root):
     cdir = tmp_path / "comm"
     cdir.mkdir()
     out = tmp_path / "job.json"
-    env = dict(os.environ, BC_COMM_TIMEOUT_S="120")
+    env = dict(os.environ, BC_COMM_TIMEOUT_S="120", BC_COMM_VERBOSE="1")
     if case.endswith("+bits"):
         case = case[:-5]
         env["BC_BITMAP_MIN_ENTRIES"] = "1"
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_rank.py"), case, str(r), str(world), str(cdir),
                                str(n), str(root), str(out)], env=env, stderr=subprocess.PIPE) for r in range(world)]
+    errs = []
     for r, p in enumerate(procs):
         _, err = p.communicate(timeout=300)
         assert p.returncode == 0, (r, err.decode()[-1500:])
+        errs.append(err.decode())
+    if case.startswith("dense"):  # which form the table exchange took (BC_COMM_VERBOSE: the root says)
+        if "BC_BITMAP_MIN_ENTRIES" not in env:
+            assert "byte-packed slices" in errs[root], errs[root][-400:]
+        elif case in ("dense_big", "dense_hot"):  # (sparse enough / so small that every entry fits the side list)
+            assert "bit-map slices" in errs[root], errs[root][-400:]
     job = json.load(open(out))
     exp_counters, exp_rows = _oracle(case, n)
     assert {k: job["counters"][k] for k in exp_counters} == exp_counters
