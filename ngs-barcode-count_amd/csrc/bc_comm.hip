@@ -96,6 +96,43 @@ __global__ void comm_sum_bits_kernel(const uint32_t* __restrict__ rows, uint32_t
   }
 }
 
+// counts below 4 as two bit planes (planes[w]: bit 0, planes[words + w]: bit 1, of entries 32 w .. 32 w + 31); a count
+// of 4 or more leaves both bits clear and goes to the list (one thread per plane word)
+__global__ void comm_pack_planes2_kernel(const uint32_t* __restrict__ counts, uint64_t len, uint64_t words, uint32_t* __restrict__ planes,
+                                         unsigned long long* cursor, uint64_t capacity, unsigned long long* __restrict__ out_idx,
+                                         uint32_t* __restrict__ out_val) {
+  uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  for (; j < words; j += step) {
+    uint32_t p0 = 0, p1 = 0;
+    for (uint32_t b = 0; b < 32u; ++b) {
+      const uint64_t i = j * 32 + b;
+      if (i >= len) break;
+      const uint32_t c = counts[i];
+      if (c < 4u) {
+        p0 |= (c & 1u) << b;
+        p1 |= (c >> 1) << b;
+      } else {
+        const unsigned long long p = atomicAdd(cursor, 1ull);
+        if (p < capacity) {
+          out_idx[p] = i;
+          out_val[p] = c;
+        }
+      }
+    }
+    planes[j] = p0;
+    planes[words + j] = p1;
+  }
+}
+__global__ void comm_unpack_planes2_kernel(const uint32_t* __restrict__ planes, uint64_t words, uint64_t len, uint32_t* __restrict__ dst) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < len; i += step) {
+    const uint32_t sh = (uint32_t)(i & 31u);
+    dst[i] = ((planes[i >> 5] >> sh) & 1u) + 2u * ((planes[words + (i >> 5)] >> sh) & 1u);
+  }
+}
+
 // the non-zero entries of a table as (index, value) pairs, in no particular order (one cursor add per wavefront)
 __global__ void comm_table_nonzero_kernel(const uint32_t* __restrict__ table, uint64_t n, unsigned long long* cursor, uint64_t capacity,
                                           unsigned long long* __restrict__ out_idx, uint32_t* __restrict__ out_val) {
@@ -286,6 +323,53 @@ struct HipOps {
     if (d_val) (void)hipFree(d_val);
     if (rc == BC_ERR_HIP) set_error("exchange: collecting the table's non-zero entries failed");
     return rc;
+  }
+  int pack_planes2(const uint32_t* counts, uint64_t len, uint32_t* planes, std::vector<uint64_t>& idx, std::vector<uint32_t>& val,
+                   uint64_t cap, bool& fits) {
+    idx.clear();
+    val.clear();
+    fits = true;
+    if (len == 0) return 0;
+    const uint64_t words = (len + 31) / 32;
+    unsigned long long *d_n = nullptr, *d_idx = nullptr;
+    uint32_t* d_val = nullptr;
+    int rc = 0;
+    if (hipMalloc((void**)&d_n, 8) != hipSuccess || hipMalloc((void**)&d_idx, cap * 8) != hipSuccess ||
+        hipMalloc((void**)&d_val, cap * 4) != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("exchange: out of device memory for the side list");
+      rc = BC_ERR_NOMEM;
+    }
+    unsigned long long need = 0;
+    if (!rc) {
+      if (hipMemsetAsync(d_n, 0, 8, st) != hipSuccess) rc = BC_ERR_HIP;
+      hipLaunchKernelGGL(comm_pack_planes2_kernel, dim3(grid_of(words)), dim3(256), 0, st, counts, len, words, planes, d_n, cap, d_idx,
+                         d_val);
+      if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&need, d_n, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+          hipStreamSynchronize(st) != hipSuccess)
+        rc = BC_ERR_HIP;
+    }
+    if (!rc) {
+      fits = need <= cap;
+      if (fits && need) {
+        idx.resize(need);
+        val.resize(need);
+        if (hipMemcpy(idx.data(), d_idx, need * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(val.data(), d_val, need * 4, hipMemcpyDeviceToHost) != hipSuccess)
+          rc = BC_ERR_HIP;
+      }
+    }
+    if (d_n) (void)hipFree(d_n);
+    if (d_idx) (void)hipFree(d_idx);
+    if (d_val) (void)hipFree(d_val);
+    if (rc == BC_ERR_HIP) set_error("exchange: packing the summed counts into bit planes failed");
+    return rc;
+  }
+  int unpack_planes2(const uint32_t* planes, uint64_t words, uint64_t len, uint32_t* dst) {
+    if (len == 0) return 0;
+    hipLaunchKernelGGL(comm_unpack_planes2_kernel, dim3(grid_of(len)), dim3(256), 0, st, planes, words, len, dst);
+    HIPC(hipGetLastError());
+    return 0;
   }
   int widen_u8(const uint8_t* src, uint64_t n, uint32_t* dst) {
     if (n == 0) return 0;
@@ -662,12 +746,13 @@ int bc_engine_reduce_all(bc_engine* e, bc_comm* c, int root, uint64_t counters[B
     // (two-level counting: the bit map travels inside the packed bytes -- table + bit --, not through a fold pass)
     uint32_t* table = (uint32_t*)bc_internal_table_unfolded(e, &ops.engine_bits);
     ops.engine_table = table;
-    bool took_bits = false;
-    if ((rc = status(reduce_tables(t, ops, table, (const uint32_t*)ops.engine_bits, bc_engine_table_entries(e), root, &took_bits))))
+    int form = 0;
+    if ((rc = status(reduce_tables(t, ops, table, (const uint32_t*)ops.engine_bits, bc_engine_table_entries(e), root, &form))))
       return rc;
     if (t.rank == root && getenv("BC_COMM_VERBOSE"))
       fprintf(stderr, "[barcode-count] table exchange over %d ranks: %s\n", t.world,
-              took_bits ? "bit-map slices + the tables' non-zero entries" : "byte-packed slices");
+              form == 0 ? "byte-packed slices" : (form == 1 ? "bit-map slices + the tables' non-zero entries, sums as bytes"
+                                                            : "bit-map slices + the tables' non-zero entries, sums as two bit planes"));
     if ((rc = bc_internal_table_now_plain(e))) return rc;  // root: the table is the job's sum; others: unspecified anyway
   }
   if ((rc = status(t.reduce_sum_u64(local, BC_NCOUNTERS, root)))) return rc;

@@ -27,6 +27,12 @@
 //                                                    unspecified) when there are more than cap
 //   int sum_bits(const uint32_t* rows, uint32_t n_rows, uint64_t words, uint64_t len, uint32_t* out)
 //                                                    out[i] = number of the n_rows bit maps (words u32 each) with bit i
+//   int pack_planes2(const uint32_t* counts, uint64_t len, uint32_t* planes, std::vector<uint64_t>& ovf_idx,
+//                    std::vector<uint32_t>& ovf_val, uint64_t cap, bool& fits)
+//                                                    planes[w] / planes[words + w] (words = (len + 31) / 32): bits 0 / 1 of
+//                                                    the counts below 4; a count of 4 or more: both bits clear and
+//                                                    (i, count) in the host lists; fits = false when more than cap such
+//   int unpack_planes2(const uint32_t* planes, uint64_t words, uint64_t len, uint32_t* dst)   dst[i] = bit0 + 2 bit1
 //   int sync()                                       everything above has finished
 #pragma once
 #include <algorithm>
@@ -116,11 +122,12 @@ int exchange_pairs(Transport& t, std::vector<uint64_t>& idx, std::vector<uint32_
 // `bits` (may be null): two-level counting -- the count of entry i is table[i] + bit i of this map.  After a short job
 // nearly every count IS its bit (the table holds the repeats only), and step 1 then sends the bit map's slices as they
 // stand -- an eighth of the bytes again, no pack pass -- with the table's few non-zero entries in the side list; used
-// when every rank's table is that sparse (at most one entry in 64), else table + bit go into the bytes.
+// when every rank's table is that sparse (at most one entry in 64), else table + bit go into the bytes.  The sums of
+// step 3 then travel as two bit planes.
 template <class Ops>
-int reduce_tables(Transport& t, Ops& ops, uint32_t* table, const uint32_t* bits, uint64_t n, int root, bool* took_bits = nullptr) {
+int reduce_tables(Transport& t, Ops& ops, uint32_t* table, const uint32_t* bits, uint64_t n, int root, int* form = nullptr) {
   const int W = t.world, me = t.rank;
-  if (took_bits) *took_bits = false;
+  if (form) *form = 0;  // 0: bytes both ways; 1: bit-map slices out, bytes to the root; 2: bit-map slices out, bit planes to the root
   if (W <= 1 || n == 0) return 0;
   Scoped<Ops> mem(ops);
   const uint64_t my_begin = slice_begin(n, W, me), my_len = slice_begin(n, W, me + 1) - my_begin;
@@ -138,7 +145,7 @@ int reduce_tables(Transport& t, Ops& ops, uint32_t* table, const uint32_t* bits,
     if ((rc = t.exchange_counts(mine.data(), theirs.data()))) return rc;
     as_bits = true;
     for (uint64_t v : theirs) as_bits = as_bits && v != 0;
-    if (took_bits) *took_bits = as_bits;
+    if (form) *form = as_bits ? 1 : 0;
   }
   uint32_t* part = mem.template get<uint32_t>((size_t)my_len + 4);
   if (!part) return -4;
@@ -178,7 +185,57 @@ int reduce_tables(Transport& t, Ops& ops, uint32_t* table, const uint32_t* bits,
     for (uint64_t& i : i_idx) i -= my_begin;
     if ((rc = ops.scatter_add(part, i_idx.data(), i_val.data(), i_idx.size()))) return rc;
   }
-  // 3. summed slices to the root, as bytes + side list
+  // 3. summed slices to the root.  In the bit-map form the sums are small (a tuple seen on every rank counts W): they
+  // travel as two bit planes -- a quarter of a byte per count -- with counts of 4 and more in the side list; all ranks
+  // vote again, and fall back to bytes together.
+  o_idx.clear();
+  o_val.clear();
+  const uint64_t my_words = (my_len + 31) / 32;
+  bool as_planes = false;
+  uint32_t* planes = nullptr;
+  if (as_bits) {
+    planes = mem.template get<uint32_t>((size_t)(2 * my_words) + 4);
+    if (!planes) return -4;
+    bool fits = false;
+    if ((rc = ops.pack_planes2(part, my_len, planes, o_idx, o_val, std::max<uint64_t>(1024, my_len / 64), fits))) return rc;
+    std::vector<uint64_t> mine((size_t)W, fits ? 1u : 0u), theirs((size_t)W, 0);
+    if ((rc = t.exchange_counts(mine.data(), theirs.data()))) return rc;
+    as_planes = true;
+    for (uint64_t v : theirs) as_planes = as_planes && v != 0;
+    if (form && as_planes) *form = 2;
+  }
+  if (as_planes) {
+    for (uint64_t& i : o_idx) i += my_begin;
+    // the root's view: every rank's two planes back to back, rank after rank
+    uint32_t* all_planes = nullptr;
+    std::vector<uint64_t> words_of((size_t)W);
+    uint64_t total_words = 0;
+    for (int r = 0; r < W; ++r) {
+      words_of[(size_t)r] = (slice_begin(n, W, r + 1) - slice_begin(n, W, r) + 31) / 32;
+      total_words += 2 * words_of[(size_t)r];
+    }
+    if (me == root) {
+      all_planes = mem.template get<uint32_t>((size_t)total_words + 4);
+      if (!all_planes) return -4;
+    }
+    for (int r = 0; r < W; ++r) {
+      sb[(size_t)r] = r == root ? 2 * my_words * 4 : 0;
+      rb[(size_t)r] = me == root ? 2 * words_of[(size_t)r] * 4 : 0;
+    }
+    if ((rc = ops.sync())) return rc;
+    if ((rc = t.all_to_all_v(planes, sb.data(), all_planes ? (void*)all_planes : (void*)planes, rb.data()))) return rc;
+    if ((rc = exchange_pairs(t, o_idx, o_val, [&](uint64_t) { return root; }, i_idx, i_val))) return rc;
+    if (me == root) {
+      uint64_t at = 0;
+      for (int r = 0; r < W; ++r) {
+        const uint64_t b = slice_begin(n, W, r), len_r = slice_begin(n, W, r + 1) - b;
+        if (len_r && (rc = ops.unpack_planes2(all_planes + at, words_of[(size_t)r], len_r, table + b))) return rc;
+        at += 2 * words_of[(size_t)r];
+      }
+      if (!i_idx.empty() && (rc = ops.scatter_add(table, i_idx.data(), i_val.data(), i_idx.size()))) return rc;
+    }
+    return ops.sync();
+  }
   o_idx.clear();
   o_val.clear();
   uint8_t* mine8 = recv;  // (my_len bytes of it: what arrived has been summed)

@@ -76,6 +76,30 @@ struct HostOps {
     fits = idx.size() <= cap;
     return 0;
   }
+  int pack_planes2(const uint32_t* counts, uint64_t len, uint32_t* planes, std::vector<uint64_t>& idx, std::vector<uint32_t>& val,
+                   uint64_t cap, bool& fits) {
+    idx.clear();
+    val.clear();
+    const uint64_t words = (len + 31) / 32;
+    for (uint64_t w = 0; w < 2 * words; ++w) planes[w] = 0;
+    for (uint64_t i = 0; i < len; ++i) {
+      const uint32_t c = counts[i];
+      if (c < 4u) {
+        planes[i >> 5] |= (c & 1u) << (i & 31);
+        planes[words + (i >> 5)] |= (c >> 1) << (i & 31);
+      } else {
+        idx.push_back(i);
+        val.push_back(c);
+      }
+    }
+    fits = idx.size() <= cap;
+    return 0;
+  }
+  int unpack_planes2(const uint32_t* planes, uint64_t words, uint64_t len, uint32_t* dst) {
+    for (uint64_t i = 0; i < len; ++i)
+      dst[i] = ((planes[i >> 5] >> (i & 31)) & 1u) + 2u * ((planes[words + (i >> 5)] >> (i & 31)) & 1u);
+    return 0;
+  }
   int widen_u8(const uint8_t* src, uint64_t n, uint32_t* dst) {
     for (uint64_t i = 0; i < n; ++i) dst[i] = src[i];
     return 0;
@@ -151,9 +175,9 @@ int main(int argc, char** argv) {
       ops.engine_table = table.data();
       ops.engine_bits = bits.data();
     }
-    bool took_bits = false;
-    rc = bc::reduce_tables(t, ops, table.data(), how.empty() ? nullptr : bits.data(), n, root, &took_bits);
-    if (rank == root) printf("form %s\n", took_bits ? "bits" : "bytes");
+    int form = 0;
+    rc = bc::reduce_tables(t, ops, table.data(), how.empty() ? nullptr : bits.data(), n, root, &form);
+    if (rank == root) printf("form %s\n", form == 0 ? "bytes" : (form == 1 ? "bits+bytes" : "bits+planes"));
     uint64_t counters[3] = {(uint64_t)rank + 1, 10, n};
     if (!rc) rc = t.reduce_sum_u64(counters, 3, root);
     if (!rc && rank == root) {

@@ -84,6 +84,8 @@ def test_tables_are_summed_onto_the_root(tmp_path, world, n, root, how):
     out = tmp_path / "sum.bin"
     said = _run_ranks(tmp_path, world, lambda r: ["tables", str(n), "42", str(root), str(out), how])
     assert ("form bits" in said) == (how == "bits"), said  # the form every rank agreed on
+    if how == "bits":  # sums above 3 are rare with two or three ranks (two bit planes carry them), not with five
+        assert ("form bits+planes" in said) == (world <= 3), said
     raw = np.fromfile(out, dtype=np.uint8)
     got = raw[: 4 * n].view(np.uint32)
     counters = raw[4 * n:].view(np.uint64)

@@ -56,6 +56,8 @@ def test_ranks_on_one_gpu_equal_the_oracle(tmp_path, case, world, n, root):
             assert "byte-packed slices" in errs[root], errs[root][-400:]
         elif case in ("dense_big", "dense_hot"):  # (sparse enough / so small that every entry fits the side list)
             assert "bit-map slices" in errs[root], errs[root][-400:]
+            if case == "dense_big":  # ... and the sums are small: two bit planes to the root
+                assert "two bit planes" in errs[root], errs[root][-400:]
     job = json.load(open(out))
     exp_counters, exp_rows = _oracle(case, n)
     assert {k: job["counters"][k] for k in exp_counters} == exp_counters
