@@ -13,7 +13,11 @@
 extern "C" __constant__ uint64_t bc_jit_addr[];
 #define BC_ADDR(field, k) bc_jit_addr[index * kAddrPerGroup + (k)]
 #define BC_PLAN_ADDR(field, k) bc_jit_addr[kMaxGroups * kAddrPerGroup + (k)]
+// ... of a table only rare paths touch: read where it is used (a volatile load is not hoisted out of the loop over the
+// tiles, where it would sit in a register the hot path is short of for the whole launch)
+#define BC_ADDR_COLD(field, k) (*reinterpret_cast<const volatile uint64_t*>(&bc_jit_addr[index * kAddrPerGroup + (k)]))
 #else
+#define BC_ADDR_COLD(field, k) field
 #define BC_ADDR(field, k) field
 #define BC_PLAN_ADDR(field, k) field
 #endif
@@ -21,13 +25,14 @@ extern "C" __constant__ uint64_t bc_jit_addr[];
 namespace bc {
 
 constexpr int kMaxGroups = 18;
-constexpr int kAddrPerGroup = 15;  // address fields of a DevGroup, in declaration order
+constexpr int kAddrPerGroup = 17;  // address fields of a DevGroup, in declaration order
 constexpr int kPlanAddrs = 1;      // ... of the DevPlan itself    // sample + 16 counted barcodes + random
 constexpr int kMaxEntries = 160;  // program entries per position class (up to three positions each)
 constexpr int kMaxRuns = 40;      // quality runs of regions_string
 constexpr int kClasses = 5;       // A, C, T, G constants + scheme-N ([AGCT]) positions
 constexpr int kMaxNW = 10;        // 32-base words per read: reads up to 320 bases
 constexpr uint32_t kFail = 0xFFFFFFFFu;
+constexpr uint32_t kDeferred = 0xFFFFFFFEu;  // Ops::nearest: the verdict comes later (bc_kernel.h: search queue)
 constexpr uint16_t kFail16 = 0xFFFFu;
 constexpr uint32_t kLhashMul1 = 0x9E3779u;  // 24-bit multipliers: keys are below 2^20 (len <= 10), so the
 constexpr uint32_t kLhashMul2 = 0x85EBCBu;  // product fits the full-rate 24-bit multiply
@@ -115,6 +120,13 @@ struct DevGroup {
   // reference count (capped at 7) in the top three bits of its first entry.  0: sixteen-byte entries.
   uint32_t tier_compact;
   uint32_t pad_;
+  // ... and a middle one between the coarse index and the full one (budgets of four mismatches and more): seed3_nb = 4
+  // blocks catch every reference within three mismatches.  One capture in a thousand needs it, but the full index's
+  // buckets (one reference in 256 each, a dozen dependent round trips for 100 k references) held its whole wavefront.
+  uint32_t seed3_nb;      // 0: none
+  uint32_t seed3_blen;
+  uint64_t seed3_off_a;
+  uint64_t seed3_list_a;
 
   BC_HD const BC_GLOBAL uint32_t* dtable() const { return reinterpret_cast<const BC_GLOBAL uint32_t*>(BC_ADDR(dtable_a, 0)); }
   BC_HD const BC_GLOBAL uint32_t* r1() const { return reinterpret_cast<const BC_GLOBAL uint32_t*>(BC_ADDR(r1_a, 1)); }
@@ -128,6 +140,8 @@ struct DevGroup {
   BC_HD const BC_GLOBAL uint32_t* odd_list() const { return reinterpret_cast<const BC_GLOBAL uint32_t*>(BC_ADDR(odd_list_a, 9)); }
   BC_HD const BC_GLOBAL uint32_t* seed2_off() const { return reinterpret_cast<const BC_GLOBAL uint32_t*>(BC_ADDR(seed2_off_a, 12)); }
   BC_HD const BC_GLOBAL uint32_t* seed2_list() const { return reinterpret_cast<const BC_GLOBAL uint32_t*>(BC_ADDR(seed2_list_a, 13)); }
+  BC_HD const BC_GLOBAL uint32_t* seed3_off() const { return reinterpret_cast<const BC_GLOBAL uint32_t*>(BC_ADDR_COLD(seed3_off_a, 15)); }
+  BC_HD const BC_GLOBAL uint32_t* seed3_list() const { return reinterpret_cast<const BC_GLOBAL uint32_t*>(BC_ADDR_COLD(seed3_list_a, 16)); }
   BC_HD const BC_GLOBAL uint32_t* tier_bkt() const { return reinterpret_cast<const BC_GLOBAL uint32_t*>(BC_ADDR(tier_bkt_a, 14)); }
   BC_HD const BC_GLOBAL uint32_t* tier_off() const { return reinterpret_cast<const BC_GLOBAL uint32_t*>(BC_ADDR(tier_off_a, 10)); }
   BC_HD const BC_GLOBAL uint32_t* tier_list() const { return reinterpret_cast<const BC_GLOBAL uint32_t*>(BC_ADDR(tier_list_a, 11)); }
@@ -176,6 +190,13 @@ struct DevPlan {
   DevGroup groups[kMaxGroups];  // sample group first (if any), then counted barcodes in order, then random
 
   BC_HD uint64_t lhash_image() const { return BC_PLAN_ADDR(lhash_a, 0); }
+  // One known barcode group and nothing else (CRISPR guides): a read's verdict IS its barcode's, so a capture that
+  // needs the search beyond one mismatch may wait in the wave's queue until four of them share one coarse-index probe
+  // (bc_kernel.h).
+  BC_HD bool defer_search() const {
+    return n_groups == 1u && !has_random && !sparse && groups[0].mode == kSetHash && groups[0].seed_nb != 0u &&
+           groups[0].seed2_nb != 0u && groups[0].seed2_nb <= 3u && groups[0].n_odd == 0u;
+  }
 #ifdef BC_EXPERIMENT
   BC_HD uint32_t abl() const { return ablate; }
 #else
@@ -189,6 +210,8 @@ constexpr int kTotalReads = 6;     // BC_TOTAL_READS
 // outcome of one read, in counter order (barcode_count_hip.h BC_*)
 enum Outcome : uint32_t {
   kMatched = 0, kConstantRegion = 1, kSampleBarcode = 2, kBarcode = 3, kDuplicate = 4, kLowQuality = 5,
+  kPending = 6,  // (not an outcome: the read's one barcode waits in the wave's search queue, bc_kernel.h; the slot is
+                 // BC_TOTAL_READS' in the counter array, which is never counted by outcome)
   kUnsupported = 7
 };
 

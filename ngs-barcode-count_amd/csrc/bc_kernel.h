@@ -89,17 +89,20 @@ __device__ __forceinline__ bool wave_scan_blocks(uint32_t nb, uint32_t blen, con
     const BC_GLOBAL uint32_t* off = off_base + (size_t)b * (nbk + 1);
     const uint32_t beg = off[val], end = off[val + 1];
     const BC_GLOBAL uint4* list = entries + (size_t)b * n_idx;
-    for (uint32_t i0 = beg; i0 < end; i0 += 256) {
-      uint4 e[4];
-      bool on[4];
+#ifndef BC_FULL_INFLIGHT
+#define BC_FULL_INFLIGHT 4
+#endif
+    for (uint32_t i0 = beg; i0 < end; i0 += 64u * BC_FULL_INFLIGHT) {
+      uint4 e[BC_FULL_INFLIGHT];
+      bool on[BC_FULL_INFLIGHT];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < BC_FULL_INFLIGHT; ++k) {
         const uint32_t i = i0 + 64u * k + lane;
         on[k] = i < end;
         e[k] = list[on[k] ? i : beg];
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < BC_FULL_INFLIGHT; ++k) {
         const uint32_t diff = (q1 ^ e[k].x) | (q2 ^ e[k].y);
         // a reference that equals the capture on an earlier block was scored there
         bool earlier = false;
@@ -119,7 +122,9 @@ __device__ __forceinline__ bool wave_scan_blocks(uint32_t nb, uint32_t blen, con
 // The coarse index (at most four long blocks, short buckets) in two memory round trips instead of two per block:
 // all bucket bounds first, then the first 64 entries of every bucket together; longer buckets finish in a loop.
 // Complete for nb - 1 mismatches: decided iff the best distance found is below nb.
-template <int kMaxBlocks>
+// kDepth: such round trips (64 entries of every bucket each) before the loops
+// kFirst: the blocks kFirst .. kFirst + kMaxBlocks - 1 of the index (a second call with the same s does the others)
+template <int kMaxBlocks, int kDepth = 1, int kFirst = 0>
 __device__ __forceinline__ bool wave_scan_blocks_wide(uint32_t nb, uint32_t blen, const BC_GLOBAL uint32_t* off_base,
                                                       const BC_GLOBAL uint32_t* list_base, uint32_t n_idx, uint32_t q1,
                                                       uint32_t q2, Nearest& s) {
@@ -131,19 +136,12 @@ __device__ __forceinline__ bool wave_scan_blocks_wide(uint32_t nb, uint32_t blen
 #pragma unroll
   for (int b = 0; b < kMaxBlocks; ++b) {
     beg[b] = end[b] = 0;
-    if ((uint32_t)b < nb) {
-      const uint32_t val = ((q1 >> (b * blen)) & bm) | (((q2 >> (b * blen)) & bm) << blen);
-      const BC_GLOBAL uint32_t* off = off_base + (size_t)b * (nbk + 1);
+    if ((uint32_t)(b + kFirst) < nb) {
+      const uint32_t val = ((q1 >> ((b + kFirst) * blen)) & bm) | (((q2 >> ((b + kFirst) * blen)) & bm) << blen);
+      const BC_GLOBAL uint32_t* off = off_base + (size_t)(b + kFirst) * (nbk + 1);
       beg[b] = off[val];
       end[b] = off[val + 1];
     }
-  }
-  uint4 e[kMaxBlocks];
-#pragma unroll
-  for (int b = 0; b < kMaxBlocks; ++b) {
-    const uint32_t i = beg[b] + lane;
-    e[b] = make_uint4(0, 0, 0, 0);
-    if ((uint32_t)b < nb) e[b] = entries[(size_t)b * n_idx + (i < end[b] ? i : (beg[b] < end[b] ? beg[b] : 0u))];
   }
   auto score = [&](const uint4& x, uint32_t b, bool on) {
     const uint32_t diff = (q1 ^ x.x) | (q2 ^ x.y);
@@ -152,13 +150,25 @@ __device__ __forceinline__ bool wave_scan_blocks_wide(uint32_t nb, uint32_t blen
     if (on && !earlier) nearest_add(s, popc(diff), x.z, diff == 0u);
   };
 #pragma unroll
+  for (int t = 0; t < kDepth; ++t) {  // (one after the other: kMaxBlocks loads in flight, not kMaxBlocks x kDepth registers)
+    uint4 e[kMaxBlocks];
+#pragma unroll
+    for (int b = 0; b < kMaxBlocks; ++b) {
+      const uint32_t i = beg[b] + 64u * t + lane;
+      e[b] = make_uint4(0, 0, 0, 0);
+      if ((uint32_t)(b + kFirst) < nb) e[b] = entries[(size_t)(b + kFirst) * n_idx + (i < end[b] ? i : (beg[b] < end[b] ? beg[b] : 0u))];
+    }
+#pragma unroll
+    for (int b = 0; b < kMaxBlocks; ++b)
+      if ((uint32_t)(b + kFirst) < nb) score(e[b], (uint32_t)(b + kFirst), beg[b] + 64u * t + lane < end[b]);
+  }
+#pragma unroll
   for (int b = 0; b < kMaxBlocks; ++b) {
-    if ((uint32_t)b >= nb) continue;
-    score(e[b], (uint32_t)b, beg[b] + lane < end[b]);
-    for (uint32_t i = beg[b] + 64u + lane; i - lane < end[b]; i += 64u) {  // wave-uniform trip count
+    if ((uint32_t)(b + kFirst) >= nb) continue;
+    for (uint32_t i = beg[b] + 64u * kDepth + lane; i - lane < end[b]; i += 64u) {  // wave-uniform trip count
       const bool on = i < end[b];
-      const uint4 x = entries[(size_t)b * n_idx + (on ? i : beg[b])];
-      score(x, (uint32_t)b, on);
+      const uint4 x = entries[(size_t)(b + kFirst) * n_idx + (on ? i : beg[b])];
+      score(x, (uint32_t)(b + kFirst), on);
     }
   }
   const uint32_t kmin = wave_min_u32(s.key);
@@ -175,8 +185,24 @@ __device__ __forceinline__ void wave_seeded_min(const DevGroup& G, uint32_t q1, 
   // make for short buckets); only otherwise is the full one, with its budget + 1 short blocks, walked
   bool decided = false;
   if (G.seed2_nb && !coarse_done) decided = wave_scan_blocks_wide<3>(G.seed2_nb, G.seed2_blen, G.seed2_off(), G.seed2_list(), G.n_idx, q1, q2, s);
+#ifndef BC_MID_DEPTH
+#define BC_MID_DEPTH 2
+#endif
+#ifndef BC_NO_MID
+  if (!decided && G.seed3_nb && !(G.seed3_nb > 4u)) {
+    // nothing within two mismatches: the middle index settles three (64 entries of each of its four buckets per round
+    // trip; a bucket of the 100 k x 20-nt index holds a hundred)
+    nearest_init(s);
+#ifdef BC_MID_PAIRS
+    wave_scan_blocks_wide<2, BC_MID_DEPTH, 0>(G.seed3_nb, G.seed3_blen, G.seed3_off(), G.seed3_list(), G.n_idx, q1, q2, s);
+    decided = wave_scan_blocks_wide<2, BC_MID_DEPTH, 2>(G.seed3_nb, G.seed3_blen, G.seed3_off(), G.seed3_list(), G.n_idx, q1, q2, s);
+#else
+    decided = wave_scan_blocks_wide<4, BC_MID_DEPTH>(G.seed3_nb, G.seed3_blen, G.seed3_off(), G.seed3_list(), G.n_idx, q1, q2, s);
+#endif
+  }
+#endif
   if (!decided) {
-    nearest_init(s);  // whatever the coarse pass met is met again
+    nearest_init(s);  // whatever the earlier passes met is met again
     wave_scan_blocks(G.seed_nb, G.seed_blen, G.seed_off(), G.seed_list(), G.n_idx, q1, q2, s);
   }
   for (uint32_t i = lane; i < G.n_odd; i += 64) {
@@ -283,6 +309,46 @@ __device__ __forceinline__ void coarse_probe_x4(const DevGroup& G, uint32_t q1, 
   vote.idx_lane = s.idx;
 }
 
+// A capture with one to four 'N's (bn; b1, b2, bn the same in every lane) through the coarse index: its 4 .. 256
+// substitutions (wave_fix_error_seeded) are four plain captures per pass of coarse_probe_x4.  A substitution the probe
+// decides (key <= blocks) has its true minimum and count; one it cannot decide has nothing that near, so any decided
+// substitution settles the capture: true, and res = the verdict.
+__device__ __forceinline__ bool coarse_with_n(const DevGroup& G, uint32_t b1, uint32_t b2, uint32_t bn, uint32_t& res_out) {
+  const uint32_t lane = lane_now();
+  const uint32_t n_n = (uint32_t)__popc(bn);
+  const uint32_t combos = 1u << (2u * n_n);
+  uint32_t best = 0xFFFFFFFFu, res = kFail;
+  bool ok = false, any_decided = false;
+  for (uint32_t c0 = 0; c0 < combos; c0 += 4u) {
+    const uint32_t c = c0 + (lane >> 4);
+    uint32_t s1 = b1 & ~bn, s2 = b2 & ~bn;
+    for (uint32_t t = 0, rem = bn; rem; ++t, rem &= rem - 1u) {  // base (c >> 2t) & 3 at the t-th 'N'
+      s1 |= ((c >> (2u * t)) & 1u) << ctz(rem);
+      s2 |= ((c >> (2u * t + 1u)) & 1u) << ctz(rem);
+    }
+    CoarseVote vote;
+    coarse_probe_x4(G, s1, s2, true, vote);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      uint32_t kk, ii;
+      bool uu;
+      coarse_segment(vote, k, kk, uu, ii);
+      if (kk <= G.seed2_nb) {
+        any_decided = true;
+        if (kk < best) {
+          best = kk;
+          ok = uu;
+          res = ii;
+        } else if (kk == best) {
+          ok = false;
+        }
+      }
+    }
+  }
+  res_out = (ok && (best == 0u || best - 1u <= G.max_err)) ? res : kFail;
+  return any_decided;
+}
+
 // A capture with up to two 'N's against plain references: 'N' is free (parse.rs:569), so its
 // distance to a reference is that of the capture with each N replaced by the reference's base
 // there.  The nearest references of the capture are therefore those of its 4 (16) substitutions
@@ -380,6 +446,12 @@ __device__ __forceinline__ void table_add(uint32_t* p) {
 #endif
 constexpr uint32_t kHotBits = BC_HOT_BITS, kHotSlots = 1u << kHotBits, kHotEmpty = 0xFFFFFFFFu;
 constexpr uint32_t kHotBytes = kHotSlots * 8u;
+// The search queue of a wavefront (plans with DevPlan::defer_search): captures that need the search beyond one mismatch
+// wait here -- {plane 1, plane 2, 'N' mask, tile and lane of the read} -- until four plain ones share one pass of the
+// coarse index; those with 'N's (filed from the top end) are judged one by one at the end of the tile's iteration.
+// Small on purpose (1 KiB per workgroup: a fifth workgroup still fits a CU next to 100-byte tiles, LDS being handed
+// out in 1,280-byte pieces); a tile with more such captures than there is room for empties the queue in between.
+constexpr uint32_t kQueueEntries = 16u, kQueueBytes = kQueueEntries * 16u;
 
 // ---- device hash set of 64-bit keys (the AHashSet<String> per tuple of info.rs:663, flattened) ----
 constexpr unsigned long long kEmptyKey = ~0ull;
@@ -510,6 +582,7 @@ struct DeviceOps {
 
   __device__ __forceinline__ bool any(bool c) const { return __any(c) != 0; }
   uint32_t abl_;  // experiment switches (0 outside BC_EXPERIMENT builds)
+  bool defer_;            // captures that need the seed indexes are handed back (kDeferred), not searched at once
   __device__ __forceinline__ void issued() const { asm volatile("" ::: "memory"); }
   // the sequence bytes are dead once the planes are built: the next tile's sequence lines can land
   __device__ __forceinline__ void sequence_consumed() const {
@@ -646,12 +719,21 @@ struct DeviceOps {
   }
   // every lane calls this; lanes with `need` get their capture resolved one after the other
   __device__ __forceinline__ uint32_t nearest(const DevGroup& G, uint32_t q1, uint32_t q2, uint32_t qn, uint32_t qx,
-                                              bool need) const {
+                                              bool need) {
     const uint32_t lane = lane_now();  // (not the member: see lane_now)
     uint32_t out = kFail;
     unsigned long long todo = __ballot(need);
     unsigned long long probed = 0;  // captures the coarse index has been asked about
-    if (G.seed_nb && G.seed2_nb && G.seed2_nb <= 3u && G.n_odd == 0u) {
+    if (defer_) {
+      // captures the seed indexes answer (no foreign byte, at most two 'N's) are not searched here: the read goes back
+      // as kPending with its capture, and the kernel's tile loop queues and judges it (match_count_body).  (A read that
+      // gets here is anchored and of good quality, and a plan with a queue has this one group: the read's verdict is
+      // this capture's.)  What is left -- foreign bytes, three 'N's and more -- is settled below.
+      const bool later = need && qx == 0u && __popc(qn) <= 2;
+      if (later) out = kDeferred;
+      todo &= ~__ballot(later);
+    }
+    if (!defer_ && G.seed_nb && G.seed2_nb && G.seed2_nb <= 3u && G.n_odd == 0u) {
       // plain captures (no 'N', no foreign byte) four at a time through the coarse index; what it cannot decide (the
       // nearest reference is three or more mismatches away, or there is none) stays in `todo` for the full search
       unsigned long long plain = __ballot(need && qn == 0u && qx == 0u);
@@ -698,44 +780,16 @@ struct DeviceOps {
       // wavefront for milliseconds in the scan of the whole set.  A substitution the probe decides (key <= blocks) has
       // its true minimum and count; one it cannot decide has nothing that near, so any decided substitution settles
       // the capture.
-      unsigned long long with_n = __ballot(need && qx == 0u && qn != 0u && __popc(qn) <= 4);
+      unsigned long long with_n = __ballot(need && qx == 0u && qn != 0u && __popc(qn) <= 4) & todo;  // (& todo: not the queued ones)
       probed |= with_n;
       while (with_n) {
         const int src = __ffsll(with_n) - 1;
         with_n &= with_n - 1;
         const uint32_t b1 = rdlane(q1, src), b2 = rdlane(q2, src), bn = rdlane(qn, src);
-        const uint32_t n_n = (uint32_t)__popc(bn);
-        const uint32_t combos = 1u << (2u * n_n);
-        uint32_t best = 0xFFFFFFFFu, res = kFail;
-        bool ok = false, any_decided = false;
-        for (uint32_t c0 = 0; c0 < combos; c0 += 4u) {
-          const uint32_t c = c0 + (lane >> 4);
-          uint32_t s1 = b1 & ~bn, s2 = b2 & ~bn;
-          for (uint32_t t = 0, rem = bn; rem; ++t, rem &= rem - 1u) {  // base (c >> 2t) & 3 at the t-th 'N'
-            s1 |= ((c >> (2u * t)) & 1u) << ctz(rem);
-            s2 |= ((c >> (2u * t + 1u)) & 1u) << ctz(rem);
-          }
-          CoarseVote vote;
-          coarse_probe_x4(G, s1, s2, true, vote);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            uint32_t kk, ii;
-            bool uu;
-            coarse_segment(vote, k, kk, uu, ii);
-            if (kk <= G.seed2_nb) {
-              any_decided = true;
-              if (kk < best) {
-                best = kk;
-                ok = uu;
-                res = ii;
-              } else if (kk == best) {
-                ok = false;
-              }
-            }
-          }
-        }
+        uint32_t res_n;
+        const bool any_decided = coarse_with_n(G, b1, b2, bn, res_n);
         if (any_decided) {
-          if ((int)lane == src) out = (ok && (best == 0u || best - 1u <= G.max_err)) ? res : kFail;
+          if ((int)lane == src) out = res_n;
           todo &= ~(1ull << src);
         }
       }
@@ -749,7 +803,7 @@ struct DeviceOps {
       const uint32_t bn = (uint32_t)__shfl((int)qn, src);
       const uint32_t bx = (uint32_t)__shfl((int)qx, src);
       // the seed index answers captures with at most two 'N's when every reference is plain
-      const bool seeded = G.seed_nb && bx == 0u && G.n_odd == 0u && __popc(bn) <= 2;
+      const bool seeded = !defer_ && G.seed_nb && bx == 0u && G.n_odd == 0u && __popc(bn) <= 2;  // (queued otherwise)
       const uint32_t r = seeded ? wave_fix_error_seeded(G, b1, b2, bn, ((probed >> src) & 1ull) != 0ull)
                                 : wave_fix_error(G, b1, b2, bn, bx, true);
       if (lane == (uint32_t)src) out = r;
@@ -778,7 +832,12 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
   __shared__ uint32_t s_cnt[kNCounters];
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
-  const uint32_t wave = tid >> 6;
+  // Plans with a search queue (DevPlan::defer_search) get the wave's number as a scalar: the tile numbers and offsets
+  // that derive from it then live in scalar registers, which is what lets their kernel fit five waves per SIMD (93
+  // vector registers; 98 and a spill without).  Elsewhere the scalar registers are the scarcer ones: config 2 ran 5 %
+  // slower with it.
+  const bool queues = pl.defer_search();
+  const uint32_t wave = queues ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)) : tid >> 6;
   if (tid < kNCounters) s_cnt[tid] = 0;
 
   const bool with_qual = pl.quality_on && !(pl.abl() & 0x8u);
@@ -813,7 +872,14 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
     }
   }
   const uint32_t two = (with_qual && pipe) ? 2u : 1u;
-  ops.tile = reinterpret_cast<uint8_t*>(smem) + lhash_vec * 16u + (hot ? kHotBytes : 0u) + wave * region * two;
+  // the waves' search queues sit between the cache and the tiles (the host reserves them whenever the plan has them:
+  // lds_tiles_for)
+  ops.defer_ = queues && !(pl.abl() & 0x200000u);
+  uint4* const dq = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(smem) + lhash_vec * 16u + (hot ? kHotBytes : 0u) + wave * kQueueBytes);
+  uint32_t dq_plain = 0, dq_n = 0;  // entries waiting: plain ones in dq[0 ..), those with 'N' in dq[kQueueEntries - 1 ..) downwards
+  uint32_t tile_seq = 0;            // tiles this wave has been through
+  ops.tile = reinterpret_cast<uint8_t*>(smem) + lhash_vec * 16u + (hot ? kHotBytes : 0u) + (queues ? (kTPB / 64) * kQueueBytes : 0u) +
+             wave * region * two;
   ops.qtile = ops.tile + (two == 2u ? region : 0u);
   ops.region = region;
   ops.lane = lane;
@@ -864,6 +930,30 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
   for (int k = 0; k < 12; ++k) ops.acc[k] = 0;
   ops.t_last = __builtin_readcyclecounter();
 #endif
+  // the workgroup's LDS counters: an index that owns (or can still claim) its slot is counted there; what is left
+  // for the table comes back
+  auto hot_count = [&](bool add, uint32_t key) -> bool {
+    uint32_t h = ((key ^ hot_seed) * 0x9E3779B1u) >> (32u - kHotBits);
+    uint32_t tag = add ? hot_tag[h] : key ^ 1u;
+#ifndef BC_HOT_ONE
+    // taken by another index: a second slot to try.  With one slot per index the guides of rank ~20-250 of a
+    // Zipf-like library owned theirs in some workgroups only (whoever comes first keeps a slot), and what was
+    // left of their adds -- one address, ~60 M/s -- decided the kernel's time: 6.84 -> 5.75 ms per 125 M reads
+    if (add && tag != key && tag != kHotEmpty) {
+      h = ((key ^ hot_seed) * 0xC2B2AE35u) >> (32u - kHotBits);
+      tag = hot_tag[h];
+    }
+#endif
+    if (add && tag == kHotEmpty) {
+      const uint32_t old = atomicCAS(&hot_tag[h], kHotEmpty, key);
+      tag = old == kHotEmpty ? key : old;
+    }
+    if (add && tag == key) {
+      atomicAdd(&hot_cnt[h], 1u);
+      add = false;
+    }
+    return add;
+  };
   for (; t < n_tiles; t += n_waves) {
     const uint64_t wfirst = t << 6;
     const uint32_t n_w = n_reads - wfirst < 64u ? (uint32_t)(n_reads - wfirst) : 64u;
@@ -898,6 +988,9 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
 
     ops.mark(8);
     uint32_t outcome = r.outcome;
+    // (outcome kPending: the read's one barcode needs the seed indexes -- ops.nearest.  It is queued at the end of this
+    // iteration and judged and counted there, or at the end of a later one when four are together, at the latest with
+    // the wave's last tile.  Until then the read is in no outcome counter; it is in TotalReads below.)
     if (pl.has_random) {
       // Results::add_count with a random barcode (info.rs:770-802): insert (tuple, random) into the
       // set; an element already present makes the read a duplicate (parse.rs:65-69)
@@ -911,7 +1004,7 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
       acc_cnt[k] += (uint32_t)__popcll(__ballot(active && outcome == k));
     }
     acc_cnt[kTotalReads] += n_w;
-    if (trace_outcome && active) {
+    if (trace_outcome && active && outcome != kPending) {
       trace_outcome[wfirst + lane] = (uint8_t)outcome;
       trace_idx[wfirst + lane] = pl.has_random ? r.dense_idx * pl.rspace + r.rcode : r.dense_idx;
     }
@@ -945,29 +1038,7 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
     first_on = 0u;
     if (!pl.has_random) {
       bool add = active && outcome == kMatched && !pl.discard_counts && !(pl.abl() & 0x4u);
-      if (hot && !pl.sparse && __any(add)) {
-        // the workgroup's LDS counters first: an index that owns (or can still claim) its slot is counted there
-        const uint32_t key = (uint32_t)r.dense_idx;
-        uint32_t h = ((key ^ hot_seed) * 0x9E3779B1u) >> (32u - kHotBits);
-        uint32_t tag = add ? hot_tag[h] : key ^ 1u;
-#ifndef BC_HOT_ONE
-        // taken by another index: a second slot to try.  With one slot per index the guides of rank ~20-250 of a
-        // Zipf-like library owned theirs in some workgroups only (whoever comes first keeps a slot), and what was
-        // left of their adds -- one address, ~60 M/s -- decided the kernel's time: 6.84 -> 5.75 ms per 125 M reads
-        if (add && tag != key && tag != kHotEmpty) {
-          h = ((key ^ hot_seed) * 0xC2B2AE35u) >> (32u - kHotBits);
-          tag = hot_tag[h];
-        }
-#endif
-        if (add && tag == kHotEmpty) {
-          const uint32_t old = atomicCAS(&hot_tag[h], kHotEmpty, key);
-          tag = old == kHotEmpty ? key : old;
-        }
-        if (add && tag == key) {
-          atomicAdd(&hot_cnt[h], 1u);
-          add = false;
-        }
-      }
+      if (hot && !pl.sparse && __any(add)) add = hot_count(add, (uint32_t)r.dense_idx);
       if (__any(add)) {
         if (add) {
           if (pl.sparse) {
@@ -984,6 +1055,88 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
       }
     }
     ops.mark(9);
+    if (ops.defer_) {
+      // (here, at the end: what the count above needed is dead by now, and the searches' registers are not added to it)
+      const DevGroup& G = pl.groups[0];
+      const uint32_t fail_k = G.type == kGroupSample ? kSampleBarcode : kBarcode;  // parse.rs:132-140
+      const uint64_t t0 = (uint64_t)blockIdx.x * (kTPB / 64) + wave;
+      // verdicts of up to four queued captures, one per lane 0 / 16 / 32 / 48 (`mine`): outcome counters, trace, count
+      auto settle = [&](bool mine, uint32_t res, uint32_t where) {
+        const bool ok = mine && res != kFail;
+        acc_cnt[kMatched] += (uint32_t)__popcll(__ballot(ok));
+        const uint32_t n_fail = (uint32_t)__popcll(__ballot(mine && !ok));
+        acc_cnt[kBarcode] += fail_k == kBarcode ? n_fail : 0u;
+        acc_cnt[kSampleBarcode] += fail_k == kSampleBarcode ? n_fail : 0u;
+        const uint64_t didx = ok ? (uint64_t)res * G.table_stride : 0ull;
+        if (trace_outcome && mine) {
+          const uint64_t rd = ((t0 + (uint64_t)(where >> 6) * n_waves) << 6) + (where & 63u);
+          trace_outcome[rd] = (uint8_t)(ok ? (uint32_t)kMatched : fail_k);
+          trace_idx[rd] = didx;
+        }
+        bool add = ok && !pl.discard_counts && !(pl.abl() & 0x4u);
+        if (hot) add = hot_count(add, (uint32_t)didx);
+        if (add) table_add_marked(pl, table, bits, didx);
+      };
+      unsigned long long pendm = __ballot(active && outcome == kPending);
+      for (;;) {
+        if (pendm) {
+          // as many of the tile's pending reads as there is room for; r carries the capture (process_read)
+          const uint32_t room = kQueueEntries - dq_plain - dq_n;
+          const bool mine = ((pendm >> lane) & 1ull) != 0ull;
+          const bool take = mine && (uint32_t)__popcll(pendm & ((1ull << lane) - 1ull)) < room;
+          const unsigned long long tm = __ballot(take), tn_m = __ballot(take && r.rcode != 0u);
+          const unsigned long long below = (1ull << lane) - 1ull;
+          if (take) {
+            const bool with_n = r.rcode != 0u;
+            const uint32_t at = with_n ? kQueueEntries - 1u - dq_n - (uint32_t)__popcll(tn_m & below)
+                                       : dq_plain + (uint32_t)__popcll(tm & ~tn_m & below);
+            dq[at] = make_uint4((uint32_t)r.dense_idx, (uint32_t)(r.dense_idx >> 32), (uint32_t)r.rcode, (tile_seq << 6) | lane);
+          }
+          dq_n += (uint32_t)__popcll(tn_m);
+          dq_plain += (uint32_t)__popcll(tm & ~tn_m);
+          pendm &= ~tm;
+          wave_lds_fence();
+        }
+        // captures with 'N': one at a time -- the coarse index over their substitutions, then the other indexes
+        while (dq_n) {
+          --dq_n;
+          const uint4 q = dq[kQueueEntries - 1u - dq_n];
+          const uint32_t b1 = rdlane(q.x, 0), b2 = rdlane(q.y, 0), bn = rdlane(q.z, 0), where = rdlane(q.w, 0);
+          uint32_t res;
+          if (!coarse_with_n(G, b1, b2, bn, res)) res = (pl.abl() & 0x100000u) ? kFail : wave_fix_error_seeded(G, b1, b2, bn, true);
+          settle(lane == 0u, res, where);
+        }
+        // plain captures: four share a pass of the coarse index; with no four together they wait for the next tile,
+        // unless this is the wave's last or the queue has to take more of this one
+        while (dq_plain >= ((tn < n_tiles && !pendm) ? 4u : 1u)) {
+          const uint32_t n_seg = dq_plain < 4u ? dq_plain : 4u;
+          dq_plain -= n_seg;
+          const uint32_t seg = lane >> 4;
+          const bool seg_on = seg < n_seg;
+          const uint4 q = dq[dq_plain + (seg_on ? seg : 0u)];
+          CoarseVote vote;
+          coarse_probe_x4(G, q.x, q.y, seg_on, vote);
+          uint32_t res = kFail;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if ((uint32_t)k >= n_seg) break;
+            uint32_t kmin, idx, rk;
+            bool uniq;
+            coarse_segment(vote, k, kmin, uniq, idx);
+            if (kmin != 0xFFFFFFFFu && kmin <= G.seed2_nb)  // decided
+              rk = (uniq && (kmin == 0u || kmin - 1u <= G.max_err)) ? idx : kFail;
+            else if (pl.abl() & 0x100000u)
+              rk = kFail;  // experiment: what the coarse index cannot decide simply fails
+            else
+              rk = wave_fix_error_seeded(G, rdlane(q.x, 16 * k), rdlane(q.y, 16 * k), 0u, true);
+            res = (int)lane == 16 * k ? rk : res;
+          }
+          settle(seg_on && (lane & 15u) == 0u, res, q.w);
+        }
+        if (!pendm) break;
+      }
+      ++tile_seq;
+    }
   }
   if (bits && first_on != 0u && ((first_old >> ((uint32_t)first_idx & 31u)) & 1u) != 0u) table_add_marked(pl, table, bits, first_idx);
 #ifdef BC_PROFILE

@@ -1062,6 +1062,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
   uint32_t inr[NW];
   low_bits<NW>(inr, len);
   bool unsupported = false;
+  uint32_t pending_n = 0;  // 'N' mask of a capture handed back for a later search (kPending)
   const bool anyx = ops.any(active && bad != 0u);
   if (anyx) {
     uint32_t hi[NW];
@@ -1367,7 +1368,13 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
           if (pre_ok && outcome == kMatched) {
             if (r[u] == kFail)
               outcome = (G.type == kGroupSample) ? kSampleBarcode : kBarcode;  // parse.rs:132-140
-            else
+            else if (r[u] == kDeferred) {
+              // single-group plans only (DevPlan::defer_search): the caller searches later; the capture goes back in
+              // the result's index and random-barcode fields, which such a read has no use for
+              outcome = kPending;
+              didx = (uint64_t)q1[u] | ((uint64_t)q2[u] << 32);
+              pending_n = qn[u];
+            } else
               didx += (uint64_t)r[u] * G.table_stride;
           }
         } else if (pre_ok && outcome == kMatched) {
@@ -1390,6 +1397,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
     res.rcode = base5_code(r1, r2, rn, pl.rnd_len);
   }
   if (unsupported) outcome = kUnsupported;
+  if (outcome == kPending) res.rcode = pending_n;
   res.outcome = outcome;
   res.dense_idx = didx;
   return res;

@@ -351,47 +351,41 @@ bool bc_plan::lower(HostDevPlan& out) const {
           else
             plain.push_back(j);
         }
-        const uint32_t nbk = 1u << (2 * blen);
-        const uint32_t bm = (1u << blen) - 1;
-        H.seed_off.assign((size_t)nb * (nbk + 1), 0);
-        H.seed_list.assign((size_t)nb * plain.size() * 4, 0);
-        for (uint32_t b = 0; b < nb; ++b) {
-          auto value = [&](uint32_t j) { return ((H.r1[j] >> (b * blen)) & bm) | (((H.r2[j] >> (b * blen)) & bm) << blen); };
-          uint32_t* off = &H.seed_off[(size_t)b * (nbk + 1)];
-          for (uint32_t j : plain) off[value(j) + 1]++;
-          for (uint32_t v = 0; v < nbk; ++v) off[v + 1] += off[v];
-          std::vector<uint32_t> cur(off, off + nbk);
-          for (uint32_t j : plain) {
-            uint32_t* e = &H.seed_list[((size_t)b * plain.size() + cur[value(j)]++) * 4];
-            e[0] = H.r1[j];
-            e[1] = H.r2[j];
-            e[2] = j;
+        // [blocks][4^bl + 1] bucket starts + [blocks][plain] entries {r1, r2, index, 0} ordered by block value
+        auto build_index = [&](uint32_t blocks, uint32_t bl, std::vector<uint32_t>& offs, std::vector<uint32_t>& list) {
+          const uint32_t nbk = 1u << (2 * bl), bm = (1u << bl) - 1;
+          offs.assign((size_t)blocks * (nbk + 1), 0);
+          list.assign((size_t)blocks * plain.size() * 4, 0);
+          for (uint32_t b = 0; b < blocks; ++b) {
+            auto value = [&](uint32_t j) { return ((H.r1[j] >> (b * bl)) & bm) | (((H.r2[j] >> (b * bl)) & bm) << bl); };
+            uint32_t* off = &offs[(size_t)b * (nbk + 1)];
+            for (uint32_t j : plain) off[value(j) + 1]++;
+            for (uint32_t v = 0; v < nbk; ++v) off[v + 1] += off[v];
+            std::vector<uint32_t> cur(off, off + nbk);
+            for (uint32_t j : plain) {
+              uint32_t* e = &list[((size_t)b * plain.size() + cur[value(j)]++) * 4];
+              e[0] = H.r1[j];
+              e[1] = H.r2[j];
+              e[2] = j;
+            }
           }
-        }
+        };
+        build_index(nb, blen, H.seed_off, H.seed_list);
         G.seed_nb = nb;
         G.seed_blen = blen;
         G.n_idx = (uint32_t)plain.size();
         G.n_odd = (uint32_t)H.odd_list.size();
         // coarser index for up to two mismatches (three blocks), in front of the full one
         if (nb > 3 && G.len / 3u >= 5u) {
-          const uint32_t b2 = std::min<uint32_t>(8u, G.len / 3u), nbk2 = 1u << (2 * b2), bm2 = (1u << b2) - 1;
-          H.seed2_off.assign((size_t)3 * (nbk2 + 1), 0);
-          H.seed2_list.assign((size_t)3 * plain.size() * 4, 0);
-          for (uint32_t b = 0; b < 3; ++b) {
-            auto value = [&](uint32_t j) { return ((H.r1[j] >> (b * b2)) & bm2) | (((H.r2[j] >> (b * b2)) & bm2) << b2); };
-            uint32_t* off = &H.seed2_off[(size_t)b * (nbk2 + 1)];
-            for (uint32_t j : plain) off[value(j) + 1]++;
-            for (uint32_t v = 0; v < nbk2; ++v) off[v + 1] += off[v];
-            std::vector<uint32_t> cur(off, off + nbk2);
-            for (uint32_t j : plain) {
-              uint32_t* e = &H.seed2_list[((size_t)b * plain.size() + cur[value(j)]++) * 4];
-              e[0] = H.r1[j];
-              e[1] = H.r2[j];
-              e[2] = j;
-            }
-          }
           G.seed2_nb = 3;
-          G.seed2_blen = b2;
+          G.seed2_blen = std::min<uint32_t>(8u, G.len / 3u);
+          build_index(G.seed2_nb, G.seed2_blen, H.seed2_off, H.seed2_list);
+        }
+        // ... and one for up to three (four blocks) between the two
+        if (G.seed2_nb && nb > 4 && G.len / 4u >= 5u) {
+          G.seed3_nb = 4;
+          G.seed3_blen = std::min<uint32_t>(8u, G.len / 4u);
+          build_index(G.seed3_nb, G.seed3_blen, H.seed3_off, H.seed3_list);
         }
         // first tier (see bc_device_plan.h): two blocks, one per half of the barcode
         const uint32_t tb = std::min<uint32_t>(8u, G.len / 2u);

@@ -53,7 +53,7 @@ struct HostSet {
   std::vector<uint8_t> rlen;
   std::vector<uint64_t> hkeys;
   std::vector<uint32_t> hvals;
-  std::vector<uint32_t> seed_off, seed_list, odd_list, tier_off, tier_list, tier_bkt, seed2_off, seed2_list;
+  std::vector<uint32_t> seed_off, seed_list, odd_list, tier_off, tier_list, tier_bkt, seed2_off, seed2_list, seed3_off, seed3_list;
 };
 
 struct HostDevPlan {

@@ -139,6 +139,39 @@ def test_config5_scale_errors_reach_every_search_tier():
     eng.close()
 
 
+def test_config5_queued_searches_carry_over_between_tiles():
+    """the search queue of a wavefront (bc_kernel.h: plans with one known set): enough reads that a wavefront goes
+    through several tiles, so captures wait in its queue from one tile to the next and the read a verdict belongs to
+    is found again from (tile, lane) -- every read's outcome against the oracle (an outcome slot nobody writes shows
+    as 0xFF), then the rows"""
+    import torch
+    import ngs_barcode_count_amd as pkg
+    w = workloads.make("config5")
+    n = 420_000  # > 64 reads x 5 waves x 4 SIMDs x 256 CUs: the first ~1,400 wavefronts get a second tile
+    R = w.read_len
+    seq, qual = w.synth.generate_host(0, n)
+    d_out = torch.full((n,), 0xFF, dtype=torch.uint8, device="cuda")
+    d_idx = torch.zeros(n, dtype=torch.int64, device="cuda")
+    eng = pkg.Engine(w.plan, device=0)
+    eng.trace(d_out.data_ptr(), d_idx.data_ptr())
+    _run(w, 0, n, eng=eng, chunk=n)
+    exp_out, exp_rows, exp_counters = _oracle_outcomes_parallel(w, seq, None)
+    got_out = d_out.cpu().numpy()
+    bad = np.nonzero(got_out != exp_out)[0]
+    assert bad.size == 0, (bad.size, bad[:5], got_out[bad[:5]], exp_out[bad[:5]])
+    got = eng.counters()
+    assert {k: got[k] for k in exp_counters} == exp_counters
+    assert eng.result_rows() == exp_rows
+    # a matched read's traced index is its guide's row
+    idx = d_idx.cpu().numpy()
+    hist = np.bincount(idx[got_out == 0], minlength=len(w.counted[0]))
+    by_seq = {t_: k for _, t_, k in exp_rows}
+    guides = [g.decode() if isinstance(g, bytes) else g for g in w.counted[0]]
+    assert sum(by_seq.values()) == int(hist.sum())
+    assert all(by_seq.get(guides[g], 0) == int(c) for g, c in enumerate(hist))
+    eng.close()
+
+
 def test_config4_bench_variant_vs_oracle():
     """config 4 as bench.py runs it: PCR copies per molecule geometric with mean 2, scattered over the job by a fixed
     permutation (geo_total = the job's read count); duplicates, distinct counts and rows against the oracle"""
