@@ -1004,7 +1004,7 @@ __device__ __forceinline__ void match_count_body(const DevPlan& pl, const uint8_
       acc_cnt[k] += (uint32_t)__popcll(__ballot(active && outcome == k));
     }
     acc_cnt[kTotalReads] += n_w;
-    if (trace_outcome && active && outcome != kPending) {
+    if (trace_outcome && active && !(queues && outcome == kPending)) {
       trace_outcome[wfirst + lane] = (uint8_t)outcome;
       trace_idx[wfirst + lane] = pl.has_random ? r.dense_idx * pl.rspace + r.rcode : r.dense_idx;
     }

@@ -1368,7 +1368,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
           if (pre_ok && outcome == kMatched) {
             if (r[u] == kFail)
               outcome = (G.type == kGroupSample) ? kSampleBarcode : kBarcode;  // parse.rs:132-140
-            else if (r[u] == kDeferred) {
+            else if (pl.defer_search() && r[u] == kDeferred) {
               // single-group plans only (DevPlan::defer_search): the caller searches later; the capture goes back in
               // the result's index and random-barcode fields, which such a read has no use for
               outcome = kPending;
@@ -1397,7 +1397,7 @@ BC_HD ReadResult process_read(const DevPlan& pl, Ops& ops, const uint32_t* seq32
     res.rcode = base5_code(r1, r2, rn, pl.rnd_len);
   }
   if (unsupported) outcome = kUnsupported;
-  if (outcome == kPending) res.rcode = pending_n;
+  if (pl.defer_search() && outcome == kPending) res.rcode = pending_n;
   res.outcome = outcome;
   res.dense_idx = didx;
   return res;
