@@ -208,7 +208,8 @@ class Run:
     contract's numbers (rank 0: complete); the legs that are NOT part of the headline (finish, box ceilings, host
     submit, ingest) are separate methods that main() calls only after the contract line is out."""
 
-    def __init__(self, name, n, steps, warmup, world, rank, local, dev, comm=None):
+    def __init__(self, name, n, steps, warmup, world, rank, local, dev, comm=None, agree=None):
+        self.agree, self.exchange_note = agree, ""  # agree(comm, why) -> (comm, note): see agree_on_transport
         import torch
         import ngs_barcode_count_amd as pkg
         from ngs_barcode_count_amd import distributed as bcdist
@@ -289,8 +290,21 @@ class Run:
         for _ in range(self.warmup):
             step()
         if world > 1:
-            # warm-up of the end-of-job exchange too: RCCL sets up its peer-to-peer connections on first use
-            eng.reduce_all(self.comm, 0)
+            # warm-up of the end-of-job exchange too: RCCL sets up its peer-to-peer connections on first use.  A failure
+            # here (on any rank) moves every rank to the message-file transport (agree_on_transport).
+            why = ""
+            try:
+                eng.reduce_all(self.comm, 0)
+            except Exception as e:  # noqa: BLE001
+                if self.agree is None:
+                    raise
+                why = "%s: %s" % (type(e).__name__, e)
+            if self.agree is not None:
+                self.comm, note = self.agree(self.comm, why)
+                if note:
+                    self.exchange_note = note
+                    eng.reset()
+                    eng.reduce_all(self.comm, 0)
         self._barrier()
         t_r = time.perf_counter()
         eng.reset()
@@ -502,6 +516,28 @@ def emit_extras(extras):
         pass
 
 
+def agree_on_transport(dist, torch, pkg, dev, rank, world, comm, why):
+    """all ranks: keep the RCCL communicator if every rank's is fine, else all switch to message files"""
+    import tempfile
+    flag = torch.tensor([0 if why else 1], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        return comm, ""
+    sys.stderr.write("[bench rank %d] RCCL transport of the library not usable (%s); the job's exchange goes through message "
+                     "files\n" % (rank, why or "another rank failed"))
+    if comm is not None:
+        try:
+            comm.close()
+        except Exception:  # noqa: BLE001
+            pass
+    box = [tempfile.mkdtemp(prefix="bc_bench_comm_") if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    whys = [None] * world
+    dist.all_gather_object(whys, why)
+    note = "message files (the library's RCCL transport failed: %s)" % "; ".join(sorted({w for w in whys if w}))[:300]
+    return pkg.Comm.host(box[0], rank, world), note
+
+
 def main():
     args = parse_args()
     env_world = os.environ.get("WORLD_SIZE")
@@ -536,25 +572,47 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    comm = None
+    comm, exchange_note = None, ""
     if world > 1:
         # the engine library's own communicator (bc_comm over RCCL): rank 0 makes the id, torch.distributed -- which the
         # timing contract needs anyway for its barrier and its max over ranks -- carries it to the others
         import ngs_barcode_count_amd as pkg
-        if one_gpu:
+        fake_failure = os.environ.get("BC_BENCH_FAKE_RCCL_FAILURE")  # TEST ONLY (with --selftest-one-gpu): the fallback below
+        if one_gpu and not fake_failure:
             import tempfile
             box = [tempfile.mkdtemp(prefix="bc_bench_comm_") if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
             comm = pkg.Comm.host(box[0], rank, world)
         else:
-            ident = torch.zeros(128, dtype=torch.uint8, device=dev)
-            if rank == 0:
-                ident.copy_(torch.frombuffer(bytearray(pkg.Comm.unique_id()), dtype=torch.uint8))
-            dist.broadcast(ident, src=0)
-            comm = pkg.Comm.rccl(bytes(ident.cpu().numpy().tobytes()), rank, world, local)
+            # If the library's RCCL transport cannot be set up, or its first exchange fails, on ANY rank, all ranks
+            # agree (through torch.distributed) to run the job's exchange over the library's other transport -- device
+            # buffers staged through message files -- and the line says so (config.exchange): a slower, honest number
+            # instead of none.  (The transport has run on one GPU only so far: DESIGN.md 6.)
+            why = ""
+            try:
+                if fake_failure:  # (the other ranks would be fine: they learn of the failure from the vote)
+                    if rank == int(fake_failure):
+                        raise RuntimeError("faked for the test")
+                else:
+                    ident = torch.zeros(128, dtype=torch.uint8, device=dev)
+                    if rank == 0:
+                        ident.copy_(torch.frombuffer(bytearray(pkg.Comm.unique_id()), dtype=torch.uint8))
+                    dist.broadcast(ident, src=0)
+                    comm = pkg.Comm.rccl(bytes(ident.cpu().numpy().tobytes()), rank, world, local)
+                    comm.barrier()
+                    got = comm.sum_u64([rank + 1], 0)
+                    if rank == 0 and got[0] != world * (world + 1) // 2:
+                        raise RuntimeError("sum over the ranks came out as %d" % got[0])
+            except Exception as e:  # noqa: BLE001 -- whatever it is, the ranks must agree on what to do next
+                why = "%s: %s" % (type(e).__name__, e)
+            comm, exchange_note = agree_on_transport(dist, torch, pkg, dev, rank, world, comm, why)
     n = args.reads or DEFAULT_READS[args.config]
-    run = Run(args.config, n, args.steps, args.warmup, world, rank, local, dev, comm)
+    agree = None
+    if world > 1 and not one_gpu:
+        agree = lambda c, why: agree_on_transport(dist, torch, pkg, dev, rank, world, c, why)  # noqa: E731
+    run = Run(args.config, n, args.steps, args.warmup, world, rank, local, dev, comm, agree)
     res = run.measure()
+    exchange_note = run.exchange_note or exchange_note
     if rank != 0:
         run.close()
         if world > 1:
@@ -578,7 +636,8 @@ def main():
         "config": {"workload": res["workload"], "config": args.config, "reads_per_step_per_gpu": n, "read_len": res["read_len"],
                    "distinct_batches": res["distinct_batches"], "resets_in_region": res["resets_in_region"],
                    "parallelism": "reads sharded over %d GPU(s), one process each; one exchange at the end through the C ABI "
-                                  "(bc_engine_reduce_all: all-to-all sum of the counter tables, RCCL over xGMI)" % world},
+                                  "(bc_engine_reduce_all: all-to-all sum of the counter tables, RCCL over xGMI)" % world,
+                   **({"exchange": exchange_note} if exchange_note else {})},
         "roofline": res["roofline"],
         "outcomes": res["outcomes"],
         **({"valid": False, "selftest": "all ranks on one GPU, message-file exchange: NOT a measurement"} if args.selftest_one_gpu else {}),

@@ -145,3 +145,21 @@ def test_bench_n_ranks_path_on_one_gpu(config, reads):
     assert one.returncode == 0, one.stderr[-3000:]
     ref = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])["outcomes"]
     assert out == ref
+
+
+def test_bench_falls_back_to_message_files_when_rccl_fails_on_one_rank():
+    """bench.py at N > 1: the library's RCCL transport failing on ONE rank (faked here) must not leave the ranks in
+    different exchanges or the driver without a line -- all of them vote, switch to the message-file transport, and the
+    line says so"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["BC_BENCH_FAKE_RCCL_FAILURE"] = "1"  # rank 1 fails
+    reads = 200_000
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-one-gpu", "--config", "config3",
+                        "--reads", str(reads), "--steps", "2", "--warmup", "1", "--no-extra", "--no-cpu"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert "faked for the test" in line["config"]["exchange"] and line["config"]["exchange"].startswith("message files")
+    assert line["outcomes"]["total_reads"] == 2 * 2 * reads and line["reduce_ms"] > 0
+    assert "not usable" in p.stderr
