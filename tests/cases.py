@@ -153,6 +153,14 @@ def build_case(name, seed=0, n=600):
         c["counted"] = [readgen.make_set(rng, 12, 32, 6), readgen.make_set(rng, 30, 8, 2)]
         c["kwargs"] = dict(min_quality=21.0, max_constant=2)
         c["reads"] = readgen.gen_reads(rng, GAP_SCHEME, n, 120, s, c["counted"], p_sub=0.01, p_n=0.002)
+    elif name == "sample_only_large":
+        # a large SAMPLE set and no counted barcode: the one-group plan whose search verdicts are queued per wavefront
+        # (bc_kernel.h), with SampleBarcode -- not Barcode -- as the failure's outcome (parse.rs:132-140)
+        c["scheme"] = "TTGTGGAAAGGACGAAACACCG[16]GTTTTAGAGCTAGAAATAGCAAGTT"
+        s = readgen.make_set(rng, 300, 16, 3)
+        c["samples"] = {x: "S%d" % i for i, x in enumerate(s)}
+        c["counted"] = None
+        c["reads"] = readgen.gen_reads(rng, c["scheme"], n, 100, s, None, p_sub=0.05, p_n=0.004)
     else:
         raise KeyError(name)
     return c
@@ -161,7 +169,7 @@ def build_case(name, seed=0, n=600):
 ALL_CASES = ["del_exact", "del_mismatch_quality", "del_dense_ties", "del_random", "example_files",
              "example_files_samples", "crispr", "large_set_ties", "large_set_many_n", "fmtn", "nosample_with_sample_file", "nosample",
              "refs_with_n_and_ragged", "other_chars", "long_gaps", "example_files_random_nosample", "raw_counted",
-             "raw_sample", "raw_all_random"]
+             "raw_sample", "raw_all_random", "sample_only_large"]
 
 RANDOM_CASES = ["del_random", "example_files", "example_files_samples", "example_files_random_nosample",
                 "raw_all_random"]
