@@ -89,20 +89,17 @@ __device__ __forceinline__ bool wave_scan_blocks(uint32_t nb, uint32_t blen, con
     const BC_GLOBAL uint32_t* off = off_base + (size_t)b * (nbk + 1);
     const uint32_t beg = off[val], end = off[val + 1];
     const BC_GLOBAL uint4* list = entries + (size_t)b * n_idx;
-#ifndef BC_FULL_INFLIGHT
-#define BC_FULL_INFLIGHT 4
-#endif
-    for (uint32_t i0 = beg; i0 < end; i0 += 64u * BC_FULL_INFLIGHT) {
-      uint4 e[BC_FULL_INFLIGHT];
-      bool on[BC_FULL_INFLIGHT];
+    for (uint32_t i0 = beg; i0 < end; i0 += 256) {
+      uint4 e[4];
+      bool on[4];
 #pragma unroll
-      for (int k = 0; k < BC_FULL_INFLIGHT; ++k) {
+      for (int k = 0; k < 4; ++k) {
         const uint32_t i = i0 + 64u * k + lane;
         on[k] = i < end;
         e[k] = list[on[k] ? i : beg];
       }
 #pragma unroll
-      for (int k = 0; k < BC_FULL_INFLIGHT; ++k) {
+      for (int k = 0; k < 4; ++k) {
         const uint32_t diff = (q1 ^ e[k].x) | (q2 ^ e[k].y);
         // a reference that equals the capture on an earlier block was scored there
         bool earlier = false;
@@ -123,8 +120,7 @@ __device__ __forceinline__ bool wave_scan_blocks(uint32_t nb, uint32_t blen, con
 // all bucket bounds first, then the first 64 entries of every bucket together; longer buckets finish in a loop.
 // Complete for nb - 1 mismatches: decided iff the best distance found is below nb.
 // kDepth: such round trips (64 entries of every bucket each) before the loops
-// kFirst: the blocks kFirst .. kFirst + kMaxBlocks - 1 of the index (a second call with the same s does the others)
-template <int kMaxBlocks, int kDepth = 1, int kFirst = 0>
+template <int kMaxBlocks, int kDepth = 1>
 __device__ __forceinline__ bool wave_scan_blocks_wide(uint32_t nb, uint32_t blen, const BC_GLOBAL uint32_t* off_base,
                                                       const BC_GLOBAL uint32_t* list_base, uint32_t n_idx, uint32_t q1,
                                                       uint32_t q2, Nearest& s) {
@@ -136,9 +132,9 @@ __device__ __forceinline__ bool wave_scan_blocks_wide(uint32_t nb, uint32_t blen
 #pragma unroll
   for (int b = 0; b < kMaxBlocks; ++b) {
     beg[b] = end[b] = 0;
-    if ((uint32_t)(b + kFirst) < nb) {
-      const uint32_t val = ((q1 >> ((b + kFirst) * blen)) & bm) | (((q2 >> ((b + kFirst) * blen)) & bm) << blen);
-      const BC_GLOBAL uint32_t* off = off_base + (size_t)(b + kFirst) * (nbk + 1);
+    if ((uint32_t)b < nb) {
+      const uint32_t val = ((q1 >> (b * blen)) & bm) | (((q2 >> (b * blen)) & bm) << blen);
+      const BC_GLOBAL uint32_t* off = off_base + (size_t)b * (nbk + 1);
       beg[b] = off[val];
       end[b] = off[val + 1];
     }
@@ -156,19 +152,19 @@ __device__ __forceinline__ bool wave_scan_blocks_wide(uint32_t nb, uint32_t blen
     for (int b = 0; b < kMaxBlocks; ++b) {
       const uint32_t i = beg[b] + 64u * t + lane;
       e[b] = make_uint4(0, 0, 0, 0);
-      if ((uint32_t)(b + kFirst) < nb) e[b] = entries[(size_t)(b + kFirst) * n_idx + (i < end[b] ? i : (beg[b] < end[b] ? beg[b] : 0u))];
+      if ((uint32_t)b < nb) e[b] = entries[(size_t)b * n_idx + (i < end[b] ? i : (beg[b] < end[b] ? beg[b] : 0u))];
     }
 #pragma unroll
     for (int b = 0; b < kMaxBlocks; ++b)
-      if ((uint32_t)(b + kFirst) < nb) score(e[b], (uint32_t)(b + kFirst), beg[b] + 64u * t + lane < end[b]);
+      if ((uint32_t)b < nb) score(e[b], (uint32_t)b, beg[b] + 64u * t + lane < end[b]);
   }
 #pragma unroll
   for (int b = 0; b < kMaxBlocks; ++b) {
-    if ((uint32_t)(b + kFirst) >= nb) continue;
+    if ((uint32_t)b >= nb) continue;
     for (uint32_t i = beg[b] + 64u * kDepth + lane; i - lane < end[b]; i += 64u) {  // wave-uniform trip count
       const bool on = i < end[b];
-      const uint4 x = entries[(size_t)(b + kFirst) * n_idx + (on ? i : beg[b])];
-      score(x, (uint32_t)(b + kFirst), on);
+      const uint4 x = entries[(size_t)b * n_idx + (on ? i : beg[b])];
+      score(x, (uint32_t)b, on);
     }
   }
   const uint32_t kmin = wave_min_u32(s.key);
@@ -185,20 +181,12 @@ __device__ __forceinline__ void wave_seeded_min(const DevGroup& G, uint32_t q1, 
   // make for short buckets); only otherwise is the full one, with its budget + 1 short blocks, walked
   bool decided = false;
   if (G.seed2_nb && !coarse_done) decided = wave_scan_blocks_wide<3>(G.seed2_nb, G.seed2_blen, G.seed2_off(), G.seed2_list(), G.n_idx, q1, q2, s);
-#ifndef BC_MID_DEPTH
-#define BC_MID_DEPTH 2
-#endif
-#ifndef BC_NO_MID
+#ifndef BC_NO_MID  // (A/B builds)
   if (!decided && G.seed3_nb && !(G.seed3_nb > 4u)) {
     // nothing within two mismatches: the middle index settles three (64 entries of each of its four buckets per round
     // trip; a bucket of the 100 k x 20-nt index holds a hundred)
     nearest_init(s);
-#ifdef BC_MID_PAIRS
-    wave_scan_blocks_wide<2, BC_MID_DEPTH, 0>(G.seed3_nb, G.seed3_blen, G.seed3_off(), G.seed3_list(), G.n_idx, q1, q2, s);
-    decided = wave_scan_blocks_wide<2, BC_MID_DEPTH, 2>(G.seed3_nb, G.seed3_blen, G.seed3_off(), G.seed3_list(), G.n_idx, q1, q2, s);
-#else
-    decided = wave_scan_blocks_wide<4, BC_MID_DEPTH>(G.seed3_nb, G.seed3_blen, G.seed3_off(), G.seed3_list(), G.n_idx, q1, q2, s);
-#endif
+    decided = wave_scan_blocks_wide<4, 2>(G.seed3_nb, G.seed3_blen, G.seed3_off(), G.seed3_list(), G.n_idx, q1, q2, s);
   }
 #endif
   if (!decided) {
